@@ -1,0 +1,805 @@
+/* oracle/ac3enc_oracle.c — TEST INFRASTRUCTURE ONLY (see orc.h).
+ *
+ * CPU restatement, written from scratch, of the reference's AC-3 encoder
+ * (/root/reference/src/ac3enc/ac3enc.cpp, tables ac3tab.h).  Integer
+ * arithmetic, 16-bit truncating stores and shift semantics follow the cited
+ * lines so that the emitted frames are meant to be bit-identical.
+ *
+ * PARITY UNPINNED: ac3enc.cpp includes <windows.h>/<crtdbg.h> and cannot be
+ * compiled in this image, and the reference holds no encoder test vectors.
+ * What IS checked (tests/test_oracle_encoder.py): every frame produced here is
+ * decoded by the real liba52 (oracle/_ref) with zero errors, both CRCs verify,
+ * the frame fills exactly, and the decoded PCM tracks the input.
+ *
+ * Differences in structure (not in results): re-entrant context instead of
+ * the reference's single static state; PSD/excitation/mask are computed once
+ * per (block, channel) and only the SNR-offset dependent tail is re-evaluated
+ * during the search (the mask does not depend on the offset, ac3enc.cpp:357-420);
+ * tables that the reference spells out are generated from their defining
+ * formulas where one exists.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "orc.h"
+#include "orc_spec_tables.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define NBLK 6
+#define MAXCH 6
+#define EXP_REUSE 0
+#define EXP_D15 1
+#define EXP_D25 2
+#define EXP_D45 3
+
+/* ---------------- tables ---------------- */
+
+static int enc_tables_ready;
+static int16_t win_q15[256];
+static int16_t cos_q15[64], sin_q15[64], xcos_q15[128], xsin_q15[128];
+static uint8_t bitrev7[128];
+static uint16_t crc_tab[256];
+static uint8_t band_of_bin[256];
+static uint8_t band_start[51];
+
+static const uint8_t band_size[50] = {       /* A/52 banding structure (ac3tab.h:165-169) */
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+    3, 3, 3, 3, 3, 3, 3, 6, 6, 6, 6, 6, 6, 12, 12, 12, 12, 24, 24, 24, 24, 24
+};
+
+static uint8_t logadd[256];                 /* A/52 latab (ac3tab.h:51-80), built from orc_spec_tables.h */
+
+static const uint16_t hear_thr[50][3] = {    /* A/52 hth (ac3tab.h:82-133), [band][fscod] */
+    { 0x04d0, 0x04f0, 0x0580 }, { 0x04d0, 0x04f0, 0x0580 }, { 0x0440, 0x0460, 0x04b0 },
+    { 0x0400, 0x0410, 0x0450 }, { 0x03e0, 0x03e0, 0x0420 }, { 0x03c0, 0x03d0, 0x03f0 },
+    { 0x03b0, 0x03c0, 0x03e0 }, { 0x03b0, 0x03b0, 0x03d0 }, { 0x03a0, 0x03b0, 0x03c0 },
+    { 0x03a0, 0x03a0, 0x03b0 }, { 0x03a0, 0x03a0, 0x03b0 }, { 0x03a0, 0x03a0, 0x03b0 },
+    { 0x03a0, 0x03a0, 0x03a0 }, { 0x0390, 0x03a0, 0x03a0 }, { 0x0390, 0x0390, 0x03a0 },
+    { 0x0390, 0x0390, 0x03a0 }, { 0x0380, 0x0390, 0x03a0 }, { 0x0380, 0x0380, 0x03a0 },
+    { 0x0370, 0x0380, 0x03a0 }, { 0x0370, 0x0380, 0x03a0 }, { 0x0360, 0x0370, 0x0390 },
+    { 0x0360, 0x0370, 0x0390 }, { 0x0350, 0x0360, 0x0390 }, { 0x0350, 0x0360, 0x0390 },
+    { 0x0340, 0x0350, 0x0380 }, { 0x0340, 0x0350, 0x0380 }, { 0x0330, 0x0340, 0x0380 },
+    { 0x0320, 0x0340, 0x0370 }, { 0x0310, 0x0320, 0x0360 }, { 0x0300, 0x0310, 0x0350 },
+    { 0x02f0, 0x0300, 0x0340 }, { 0x02f0, 0x02f0, 0x0330 }, { 0x02f0, 0x02f0, 0x0320 },
+    { 0x02f0, 0x02f0, 0x0310 }, { 0x0300, 0x02f0, 0x0300 }, { 0x0310, 0x0300, 0x02f0 },
+    { 0x0340, 0x0320, 0x02f0 }, { 0x0390, 0x0350, 0x02f0 }, { 0x03e0, 0x0390, 0x0300 },
+    { 0x0420, 0x03e0, 0x0310 }, { 0x0460, 0x0420, 0x0330 }, { 0x0490, 0x0450, 0x0350 },
+    { 0x04a0, 0x04a0, 0x03c0 }, { 0x0460, 0x0490, 0x0410 }, { 0x0440, 0x0460, 0x0470 },
+    { 0x0440, 0x0440, 0x04a0 }, { 0x0520, 0x0480, 0x0460 }, { 0x0800, 0x0630, 0x0440 },
+    { 0x0840, 0x0840, 0x0450 }, { 0x0840, 0x0840, 0x04e0 }
+};
+
+static const uint8_t bap_of_addr[64] = {     /* A/52 baptab (ac3tab.h:135-143) */
+    0, 1, 1, 1, 1, 1, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 9, 9, 9, 9, 10,
+    10, 10, 10, 11, 11, 11, 11, 12, 12, 12, 12, 13, 13, 13, 13, 14, 14, 14, 14, 14, 14, 14, 14, 15,
+    15, 15, 15, 15, 15, 15, 15, 15
+};
+
+/* ac3enc.cpp:428-439 */
+static int16_t q15_trunc(float a)
+{
+    int v = (int)(a * (float)(1 << 15));
+    if (v < -32767) v = -32767; else if (v > 32767) v = 32767;
+    return (int16_t)v;
+}
+
+static double kbd_i0(double x)
+{
+    double b = 1;
+    for (int i = 100; i > 0; i--) b = b * x / (i * i) + 1;
+    return b;
+}
+
+static void enc_build_tables(void)
+{
+    int i, j, k, l;
+    if (enc_tables_ready) return;
+    orc_build_logadd(logadd);
+
+    /* ac3tab.h:15-48 (ac3_window): the 256 Q15 entries equal
+     * floor(32768 * w[i]) of the alpha=5 Kaiser-Bessel-derived window that
+     * liba52/imdct.c:364-372 builds (checked entry by entry in this container). */
+    {
+        double acc = 0, cum[256];
+        for (i = 0; i < 256; i++) {
+            acc += kbd_i0(i * (256 - i) * (5 * M_PI / 256) * (5 * M_PI / 256));
+            cum[i] = acc;
+        }
+        acc++;
+        for (i = 0; i < 256; i++) win_q15[i] = (int16_t)floor(32768.0 * sqrt(cum[i] / acc));
+    }
+
+    /* ac3enc.cpp:441-459 (fft_init(7)); cos()/sin() on a float argument resolve
+     * to the float overloads in the reference's C++ translation unit */
+    for (i = 0; i < 64; i++) {
+        float alpha = (float)(2 * M_PI * (float)i / (float)128);
+        cos_q15[i] = q15_trunc(cosf(alpha));
+        sin_q15[i] = q15_trunc(sinf(alpha));
+    }
+    for (i = 0; i < 128; i++) {
+        int m = 0;
+        for (j = 0; j < 7; j++) m |= ((i >> j) & 1) << (6 - j);
+        bitrev7[i] = (uint8_t)m;
+    }
+    /* ac3enc.cpp:1098-1102 */
+    for (i = 0; i < 128; i++) {
+        float alpha = (float)(2 * M_PI * (i + 1.0 / 8.0) / (float)512);
+        xcos_q15[i] = q15_trunc(-cosf(alpha));
+        xsin_q15[i] = q15_trunc(-sinf(alpha));
+    }
+    /* ac3enc.cpp:977-993 */
+    k = l = 0;
+    for (i = 0; i < 50; i++) {
+        band_start[i] = (uint8_t)l;
+        for (j = 0; j < band_size[i]; j++) band_of_bin[k++] = (uint8_t)i;
+        l += band_size[i];
+    }
+    band_start[50] = 0;
+    /* ac3enc.cpp:996-1016: CRC-16, x^16 + x^15 + x^2 + 1, MSB first */
+    for (i = 0; i < 256; i++) {
+        unsigned c = (unsigned)i << 8;
+        for (k = 0; k < 8; k++) c = (c & 0x8000) ? (((c << 1) & 0xffff) ^ 0x8005) : (c << 1);
+        crc_tab[i] = (uint16_t)c;
+    }
+    enc_tables_ready = 1;
+}
+
+void orc_ac3enc_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128, uint16_t *crc256)
+{
+    enc_build_tables();
+    memcpy(costab64, cos_q15, sizeof cos_q15);
+    memcpy(sintab64, sin_q15, sizeof sin_q15);
+    memcpy(xcos128, xcos_q15, sizeof xcos_q15);
+    memcpy(xsin128, xsin_q15, sizeof xsin_q15);
+    memcpy(crc256, crc_tab, sizeof crc_tab);
+}
+
+/* ---------------- context ---------------- */
+
+typedef struct { uint8_t *buf; uint32_t nbits; } bitw;
+
+struct orc_ac3enc {
+    int nch_all, nfbw, lfe, lfe_ch, acmod, fscod, halfrate, bsid, frmsizecod, frame_words;
+    int nb_coefs[MAXCH];
+    int chbwcod[MAXCH];
+    int16_t last[MAXCH][256];
+    int csnroffst, fsnroffst;
+    /* fixed allocation codes (ac3enc.cpp:861-869) */
+    int sdecaycod, fdecaycod, sgaincod, dbkneecod, floorcod, fgaincod;
+
+    int32_t mdct[NBLK][MAXCH][256];
+    uint8_t expo[NBLK][MAXCH][256];
+    uint8_t enc_exp[NBLK][MAXCH][256];
+    uint8_t bap[NBLK][MAXCH][256];
+    uint8_t strat[NBLK][MAXCH];
+    int8_t shift[NBLK][MAXCH];
+    int16_t psd[NBLK][MAXCH][256];
+    int16_t mask[NBLK][MAXCH][50];
+};
+
+/* ---------------- MDCT (ac3enc.cpp:462-603) ---------------- */
+
+typedef struct { int16_t re, im; } c16;
+
+static inline void bfly(c16 *p, c16 *q, int bx, int by, int ax, int ay)
+{
+    /* ac3enc.cpp:462-474: halved sum/difference, arithmetic shifts, 16-bit stores */
+    p->re = (int16_t)((bx + ax) >> 1);
+    p->im = (int16_t)((by + ay) >> 1);
+    q->re = (int16_t)((bx - ax) >> 1);
+    q->im = (int16_t)((by - ay) >> 1);
+}
+
+static void fft128_q15(c16 *z)
+{
+    int j, l, nblocks, nloops;
+    for (j = 0; j < 128; j++) {
+        int k = bitrev7[j];
+        if (k < j) { c16 t = z[k]; z[k] = z[j]; z[j] = t; }
+    }
+    for (j = 0; j < 128; j += 2)                                   /* pass 0 */
+        bfly(&z[j], &z[j + 1], z[j].re, z[j].im, z[j + 1].re, z[j + 1].im);
+    for (j = 0; j < 128; j += 4) {                                 /* pass 1: twiddles 1 and -j */
+        bfly(&z[j], &z[j + 2], z[j].re, z[j].im, z[j + 2].re, z[j + 2].im);
+        bfly(&z[j + 1], &z[j + 3], z[j + 1].re, z[j + 1].im, z[j + 3].im, -z[j + 3].re);
+    }
+    nblocks = 16;
+    nloops = 4;
+    do {                                                           /* passes 2..6 */
+        c16 *p = z, *q = z + nloops;
+        for (j = 0; j < nblocks; j++) {
+            bfly(p, q, p->re, p->im, q->re, q->im);
+            p++; q++;
+            for (l = nblocks; l < 64; l += nblocks) {
+                int c = cos_q15[l], s = -sin_q15[l];
+                int tr = (c * q->re - s * q->im) >> 15;            /* ac3enc.cpp:478-481 */
+                int ti = (c * q->im + q->re * s) >> 15;
+                bfly(p, q, p->re, p->im, tr, ti);
+                p++; q++;
+            }
+            p += nloops; q += nloops;
+        }
+        nblocks >>= 1;
+        nloops <<= 1;
+    } while (nblocks);
+}
+
+void orc_ac3enc_mdct512(int32_t *out, const int16_t *in)
+{
+    int16_t rot[512];
+    c16 x[128];
+    int i;
+    enc_build_tables();
+    for (i = 0; i < 128; i++) rot[i] = (int16_t)(-in[i + 384]);
+    for (i = 128; i < 512; i++) rot[i] = in[i - 128];
+    for (i = 0; i < 128; i++) {                                    /* pre-rotation :587-591 */
+        int re = ((int)rot[2 * i] - (int)rot[511 - 2 * i]) >> 1;
+        int im = (-((int)rot[256 + 2 * i] - (int)rot[255 - 2 * i])) >> 1;
+        int c = -xcos_q15[i], s = xsin_q15[i];
+        x[i].re = (int16_t)((re * c - im * s) >> 15);
+        x[i].im = (int16_t)((re * s + c * im) >> 15);
+    }
+    fft128_q15(x);
+    for (i = 0; i < 128; i++) {                                    /* post-rotation :596-602 */
+        int re = x[i].re, im = x[i].im, s = xsin_q15[i], c = xcos_q15[i];
+        out[2 * i] = (re * c + s * im) >> 15;
+        out[255 - 2 * i] = (re * s - im * c) >> 15;
+    }
+}
+
+static inline int ilog2(unsigned v)                                /* ac3enc.cpp:1539-1567 */
+{
+    int n = 0;
+    while (v >>= 1) n++;
+    return n;
+}
+
+/* ---------------- exponents (ac3enc.cpp:606-761) ---------------- */
+
+static void choose_strategies(orc_ac3enc_t *s, int ch)
+{
+    int b, j;
+    s->strat[0][ch] = 1;
+    for (b = 1; b < NBLK; b++) {
+        int d = 0;
+        for (j = 0; j < 256; j++) d += abs((int)s->expo[b][ch][j] - (int)s->expo[b - 1][ch][j]);
+        s->strat[b][ch] = d > 1000 ? 1 : EXP_REUSE;
+    }
+    if (ch == s->lfe_ch) return;
+    for (b = 0; b < NBLK;) {
+        int e = b + 1;
+        while (e < NBLK && s->strat[e][ch] == EXP_REUSE) e++;
+        s->strat[b][ch] = (e - b == 1) ? EXP_D45 : (e - b <= 3) ? EXP_D25 : EXP_D15;
+        b = e;
+    }
+}
+
+static int constrain_exponents(uint8_t *out, const uint8_t *in, int n, int strategy)
+{
+    int gs = strategy == EXP_D15 ? 1 : strategy == EXP_D25 ? 2 : 4;
+    int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3, i, j, k, again;
+    uint8_t g[256];
+
+    g[0] = in[0];
+    for (i = 1, k = 1; i <= ng; i++, k += gs) {
+        int m = in[k];
+        for (j = 1; j < gs; j++) if (in[k + j] < m) m = in[k + j];
+        g[i] = (uint8_t)m;
+    }
+    if (g[0] > 15) g[0] = 15;
+    do {                                                           /* ac3enc.cpp:727-745 */
+        again = 0;
+        for (i = 1; i <= ng; i++) {
+            int d = (int)g[i] - (int)g[i - 1];
+            if (d > 2) g[i] = (uint8_t)(g[i - 1] + 2);
+            else if (d < -2) { again = 1; g[i - 1] = (uint8_t)(g[i] + 2); }
+        }
+    } while (again);
+    out[0] = g[0];
+    for (i = 1, k = 1; i <= ng; i++, k += gs)
+        for (j = 0; j < gs; j++) out[k + j] = g[i];
+    return 4 + (ng / 3) * 7;
+}
+
+/* ---------------- bit allocation (ac3enc.cpp:183-421, 764-975) ---------------- */
+
+typedef struct { int sdecay, fdecay, sgain, dbknee, floor, fgain; } ba_par;
+
+static inline int lowcomp_step(int a, int b0, int b1, int bin)     /* ac3enc.cpp:183-215 */
+{
+    if (bin < 7) {
+        if (b0 + 256 == b1) a = 384;
+        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
+    } else if (bin < 20) {
+        if (b0 + 256 == b1) a = 320;
+        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
+    } else {
+        a -= 128; if (a < 0) a = 0;
+    }
+    return a;
+}
+
+/* PSD, band PSD, excitation and mask for one channel-block; start is always 0
+ * (no coupling channel in this encoder). */
+static void compute_mask(const orc_ac3enc_t *s, const ba_par *p, const uint8_t *exp, int end,
+                         int is_lfe, int16_t *psd, int16_t *mask)
+{
+    int16_t bndpsd[50], excite[50];
+    int bin, j, k, v, lowcomp = 0, fast = 0, slow = 0, begin, bndend, end1;
+
+    for (bin = 0; bin < end; bin++) psd[bin] = (int16_t)(3072 - ((int8_t)exp[bin] << 7));
+
+    j = 0; k = 0;                                                  /* PSD integration :243-276 */
+    do {
+        v = psd[j++];
+        end1 = band_start[k + 1] < end ? band_start[k + 1] : end;
+        for (; j < end1; j++) {
+            int c = v - psd[j], a;
+            if (c >= 0) { a = c >> 1; if (a > 255) a = 255; v = v + logadd[a]; }
+            else { a = (-c) >> 1; if (a > 255) a = 255; v = psd[j] + logadd[a]; }
+        }
+        bndpsd[k++] = (int16_t)v;
+    } while (end > band_start[k]);
+
+    bndend = band_of_bin[end - 1] + 1;                             /* excitation :279-353 */
+    lowcomp = lowcomp_step(lowcomp, bndpsd[0], bndpsd[1], 0);
+    excite[0] = (int16_t)(bndpsd[0] - p->fgain - lowcomp);
+    lowcomp = lowcomp_step(lowcomp, bndpsd[1], bndpsd[2], 1);
+    excite[1] = (int16_t)(bndpsd[1] - p->fgain - lowcomp);
+    begin = 7;
+    for (bin = 2; bin < 7; bin++) {
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
+        fast = bndpsd[bin] - p->fgain;
+        slow = bndpsd[bin] - p->sgain;
+        excite[bin] = (int16_t)(fast - lowcomp);
+        if (!(is_lfe && bin == 6) && bndpsd[bin] <= bndpsd[bin + 1]) { begin = bin + 1; break; }
+    }
+    end1 = bndend > 22 ? 22 : bndend;
+    for (bin = begin; bin < end1; bin++) {
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
+        fast -= p->fdecay; v = bndpsd[bin] - p->fgain; if (fast < v) fast = v;
+        slow -= p->sdecay; v = bndpsd[bin] - p->sgain; if (slow < v) slow = v;
+        v = fast - lowcomp; if (slow > v) v = slow;
+        excite[bin] = (int16_t)v;
+    }
+    for (bin = 22; bin < bndend; bin++) {
+        fast -= p->fdecay; v = bndpsd[bin] - p->fgain; if (fast < v) fast = v;
+        slow -= p->sdecay; v = bndpsd[bin] - p->sgain; if (slow < v) slow = v;
+        excite[bin] = (int16_t)(fast > slow ? fast : slow);
+    }
+    for (bin = 0; bin < bndend; bin++) {                           /* masking curve :357-367 */
+        int v1 = excite[bin], t = p->dbknee - bndpsd[bin];
+        if (t > 0) v1 += t >> 2;
+        v = hear_thr[bin >> s->halfrate][s->fscod];
+        mask[bin] = (int16_t)(v1 > v ? v1 : v);
+    }
+}
+
+/* offset-dependent tail (ac3enc.cpp:393-420) + mantissa bit count (:764-810).
+ * cnt[] are the three grouping counters, shared by the channels of a block. */
+static int alloc_and_count(const int16_t *psd, const int16_t *mask, int end, int snroffset, int floorv,
+                           uint8_t *bap, int cnt[3])
+{
+    int i = 0, j = 0, bits = 0;
+    do {
+        int v = mask[j] - snroffset - floorv, end1;
+        if (v < 0) v = 0;
+        v = (v & 0x1fe0) + floorv;
+        end1 = band_start[j] + band_size[j];
+        if (end1 > end) end1 = end;
+        for (; i < end1; i++) {
+            int a = (psd[i] - v) >> 5, b;
+            a = a < 0 ? 0 : a > 63 ? 63 : a;
+            b = bap_of_addr[a];
+            bap[i] = (uint8_t)b;
+            switch (b) {
+            case 0: break;
+            case 1: if (cnt[0] == 0) bits += 5; if (++cnt[0] == 3) cnt[0] = 0; break;
+            case 2: if (cnt[1] == 0) bits += 7; if (++cnt[1] == 3) cnt[1] = 0; break;
+            case 3: bits += 3; break;
+            case 4: if (cnt[2] == 0) bits += 7; if (++cnt[2] == 2) cnt[2] = 0; break;
+            case 14: bits += 14; break;
+            case 15: bits += 16; break;
+            default: bits += b - 1; break;
+            }
+        }
+    } while (end > band_start[j++]);
+    return bits;
+}
+
+static int try_offsets(orc_ac3enc_t *s, uint8_t bap[NBLK][MAXCH][256], int frame_bits, int floorv,
+                       int csnr, int fsnr)
+{
+    int snroffset = (((csnr - 15) << 4) + fsnr) << 2, b, ch;
+    for (b = 0; b < NBLK; b++) {
+        int cnt[3] = { 0, 0, 0 };
+        for (ch = 0; ch < s->nch_all; ch++)
+            frame_bits += alloc_and_count(s->psd[b][ch], s->mask[b][ch], s->nb_coefs[ch], snroffset,
+                                          floorv, bap[b][ch], cnt);
+    }
+    return 16 * s->frame_words - frame_bits;
+}
+
+static int search_allocation(orc_ac3enc_t *s, int frame_bits)
+{
+    static const int acmod_extra[8] = { 0, 0, 2, 2, 2, 4, 2, 4 };
+    uint8_t (*tmp)[MAXCH][256] = (uint8_t (*)[MAXCH][256])malloc(sizeof s->bap);
+    ba_par p;
+    int b, ch, csnr, fsnr;
+
+    s->sdecaycod = 2; s->fdecaycod = 1; s->sgaincod = 1; s->dbkneecod = 2; s->floorcod = 4; s->fgaincod = 4;
+    p.sdecay = (15 + 2 * s->sdecaycod) >> s->halfrate;             /* sdecaytab, ac3tab.h:145 */
+    p.fdecay = (63 + 20 * s->fdecaycod) >> s->halfrate;            /* fdecaytab :149 */
+    { static const int sg[4] = { 0x540, 0x4d8, 0x478, 0x410 }; p.sgain = sg[s->sgaincod]; }
+    { static const int dk[4] = { 0x000, 0x700, 0x900, 0xb00 }; p.dbknee = dk[s->dbkneecod]; }
+    { static const int fl[8] = { 0x2f0, 0x2b0, 0x270, 0x230, 0x1f0, 0x170, 0x0f0, 0xf800 }; p.floor = fl[s->floorcod]; }
+    p.fgain = 128 * (s->fgaincod + 1);                             /* fgaintab :161 */
+
+    /* fixed side information (ac3enc.cpp:880-916) */
+    frame_bits += 65 + acmod_extra[s->acmod];
+    for (b = 0; b < NBLK; b++) {
+        frame_bits += s->nfbw * 2 + 2;
+        if (s->acmod == 2) frame_bits++;
+        frame_bits += 2 * s->nfbw;
+        if (s->lfe) frame_bits++;
+        for (ch = 0; ch < s->nfbw; ch++)
+            if (s->strat[b][ch] != EXP_REUSE) frame_bits += 6 + 2;
+        frame_bits += 1 + 1 + 2;
+    }
+    frame_bits++;
+    frame_bits += 2 * 4 + 3 + 6 + s->nch_all * (4 + 3);
+    frame_bits += 2;
+    frame_bits += 16;
+
+    for (b = 0; b < NBLK; b++)
+        for (ch = 0; ch < s->nch_all; ch++)
+            compute_mask(s, &p, s->enc_exp[b][ch], s->nb_coefs[ch], ch == s->lfe_ch,
+                         s->psd[b][ch], s->mask[b][ch]);
+
+    /* search order and acceptance exactly as ac3enc.cpp:921-967 */
+    csnr = s->csnroffst;
+    while (csnr >= 0 && try_offsets(s, s->bap, frame_bits, p.floor, csnr, 0) < 0) csnr -= 4;
+    if (csnr < 0) { free(tmp); return -1; }
+    while (csnr + 4 <= 63 && try_offsets(s, tmp, frame_bits, p.floor, csnr + 4, 0) >= 0) {
+        csnr += 4; memcpy(s->bap, tmp, sizeof s->bap);
+    }
+    while (csnr + 1 <= 63 && try_offsets(s, tmp, frame_bits, p.floor, csnr + 1, 0) >= 0) {
+        csnr++; memcpy(s->bap, tmp, sizeof s->bap);
+    }
+    fsnr = 0;
+    while (fsnr + 4 <= 15 && try_offsets(s, tmp, frame_bits, p.floor, csnr, fsnr + 4) >= 0) {
+        fsnr += 4; memcpy(s->bap, tmp, sizeof s->bap);
+    }
+    while (fsnr + 1 <= 15 && try_offsets(s, tmp, frame_bits, p.floor, csnr, fsnr + 1) >= 0) {
+        fsnr++; memcpy(s->bap, tmp, sizeof s->bap);
+    }
+    s->csnroffst = csnr;
+    s->fsnroffst = fsnr;
+    free(tmp);
+    return 0;
+}
+
+/* ---------------- bit writer (replaces ac3enc.cpp:111-181) ---------------- */
+
+static inline void put(bitw *w, int n, unsigned v)
+{
+    while (n--) {
+        if ((v >> n) & 1) w->buf[w->nbits >> 3] |= (uint8_t)(0x80 >> (w->nbits & 7));
+        w->nbits++;
+    }
+}
+
+/* ---------------- quantisers (ac3enc.cpp:1150-1190) ---------------- */
+
+static inline int quant_sym(int c, int e, int levels)
+{
+    int v;
+    e &= 31;                                   /* x86 shift-count masking; c == 0 whenever e > 24 */
+    if (c >= 0) { v = (levels * (c << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) + v; }
+    else { v = (levels * ((-c) << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) - v; }
+    return v;
+}
+
+static inline int quant_asym(int c, int e, int qbits)
+{
+    int lshift = e + qbits - 24, v, m;
+    if (lshift >= 0) v = (int)((unsigned)c << (lshift & 31));
+    else v = c >> ((-lshift) & 31);
+    v = (v + 1) >> 1;
+    m = 1 << (qbits - 1);
+    if (v >= m) v = m - 1;
+    return v & ((1 << qbits) - 1);
+}
+
+/* ---------------- frame assembly (ac3enc.cpp:1113-1147, 1194-1502, 1599-1638) ---------------- */
+
+static void write_block(orc_ac3enc_t *s, bitw *w, int blk)
+{
+    uint16_t q[MAXCH][256];
+    uint16_t *slot3 = NULL, *slot5 = NULL, *slot11 = NULL;
+    int n3 = 0, n5 = 0, n11 = 0, ch, i;
+
+    for (ch = 0; ch < s->nfbw; ch++) put(w, 1, 0);                 /* blksw */
+    for (ch = 0; ch < s->nfbw; ch++) put(w, 1, 1);                 /* dithflag */
+    put(w, 1, 0);                                                  /* dynrnge */
+    if (blk == 0) { put(w, 1, 1); put(w, 1, 0); } else put(w, 1, 0);   /* cplstre, cplinu */
+    if (s->acmod == 2) {
+        if (blk == 0) { put(w, 1, 1); put(w, 4, 0); } else put(w, 1, 0);
+    }
+    for (ch = 0; ch < s->nfbw; ch++) put(w, 2, s->strat[blk][ch]);
+    if (s->lfe) put(w, 1, s->strat[blk][s->lfe_ch]);
+    for (ch = 0; ch < s->nfbw; ch++)
+        if (s->strat[blk][ch] != EXP_REUSE) put(w, 6, s->chbwcod[ch]);
+
+    for (ch = 0; ch < s->nch_all; ch++) {                          /* exponents :1261-1314 */
+        int st = s->strat[blk][ch], gs, ng, prev;
+        const uint8_t *e = s->enc_exp[blk][ch];
+        if (st == EXP_REUSE) continue;
+        gs = st == EXP_D15 ? 1 : st == EXP_D25 ? 2 : 4;
+        ng = (s->nb_coefs[ch] + gs * 3 - 4) / (3 * gs);
+        prev = e[0];
+        put(w, 4, prev);
+        e++;
+        for (i = 0; i < ng; i++) {
+            int d0, d1, d2;
+            d0 = e[0] - prev + 2; prev = e[0]; e += gs;
+            d1 = e[0] - prev + 2; prev = e[0]; e += gs;
+            d2 = e[0] - prev + 2; prev = e[0]; e += gs;
+            put(w, 7, (d0 * 5 + d1) * 5 + d2);
+        }
+        if (ch != s->lfe_ch) put(w, 2, 0);                         /* gainrng */
+    }
+
+    put(w, 1, blk == 0);                                           /* baie */
+    if (blk == 0) {
+        put(w, 2, s->sdecaycod); put(w, 2, s->fdecaycod); put(w, 2, s->sgaincod);
+        put(w, 2, s->dbkneecod); put(w, 3, s->floorcod);
+    }
+    put(w, 1, blk == 0);                                           /* snroffste */
+    if (blk == 0) {
+        put(w, 6, s->csnroffst);
+        for (ch = 0; ch < s->nch_all; ch++) { put(w, 4, s->fsnroffst); put(w, 3, s->fgaincod); }
+    }
+    put(w, 1, 0);                                                  /* deltbaie */
+    put(w, 1, 0);                                                  /* skiple */
+
+    for (ch = 0; ch < s->nch_all; ch++)                            /* quantise :1347-1457 */
+        for (i = 0; i < s->nb_coefs[ch]; i++) {
+            int c = s->mdct[blk][ch][i], e = s->enc_exp[blk][ch][i] - s->shift[blk][ch];
+            int b = s->bap[blk][ch][i], v;
+            switch (b) {
+            case 0: v = 0; break;
+            case 1:
+                v = quant_sym(c, e, 3);
+                if (n3 == 0) { slot3 = &q[ch][i]; v = 9 * v; n3 = 1; }
+                else if (n3 == 1) { *slot3 += 3 * v; n3 = 2; v = 128; }
+                else { *slot3 += v; n3 = 0; v = 128; }
+                break;
+            case 2:
+                v = quant_sym(c, e, 5);
+                if (n5 == 0) { slot5 = &q[ch][i]; v = 25 * v; n5 = 1; }
+                else if (n5 == 1) { *slot5 += 5 * v; n5 = 2; v = 128; }
+                else { *slot5 += v; n5 = 0; v = 128; }
+                break;
+            case 3: v = quant_sym(c, e, 7); break;
+            case 4:
+                v = quant_sym(c, e, 11);
+                if (n11 == 0) { slot11 = &q[ch][i]; v = 11 * v; n11 = 1; }
+                else { *slot11 += v; n11 = 0; v = 128; }
+                break;
+            case 5: v = quant_sym(c, e, 15); break;
+            case 14: v = quant_asym(c, e, 14); break;
+            case 15: v = quant_asym(c, e, 16); break;
+            default: v = quant_asym(c, e, b - 1); break;
+            }
+            q[ch][i] = (uint16_t)v;
+        }
+
+    for (ch = 0; ch < s->nch_all; ch++)                            /* emit :1460-1501 */
+        for (i = 0; i < s->nb_coefs[ch]; i++) {
+            int b = s->bap[blk][ch][i], v = q[ch][i];
+            switch (b) {
+            case 0: break;
+            case 1: if (v != 128) put(w, 5, v); break;
+            case 2: if (v != 128) put(w, 7, v); break;
+            case 3: put(w, 3, v); break;
+            case 4: if (v != 128) put(w, 7, v); break;
+            case 14: put(w, 14, v); break;
+            case 15: put(w, 16, v); break;
+            default: put(w, b - 1, v); break;
+            }
+        }
+}
+
+static unsigned crc_run(const uint8_t *d, int n, unsigned crc)
+{
+    for (int i = 0; i < n; i++) crc = (crc_tab[d[i] ^ (crc >> 8)] ^ (crc << 8)) & 0xffff;
+    return crc;
+}
+
+static unsigned gf_mul(unsigned a, unsigned b, unsigned poly)      /* ac3enc.cpp:1513-1524 */
+{
+    unsigned c = 0;
+    while (a) {
+        if (a & 1) c ^= b;
+        a >>= 1;
+        b <<= 1;
+        if (b & (1u << 16)) b ^= poly;
+    }
+    return c;
+}
+
+static unsigned gf_pow(unsigned a, unsigned n, unsigned poly)
+{
+    unsigned r = 1;
+    while (n) {
+        if (n & 1) r = gf_mul(r, a, poly);
+        a = gf_mul(a, a, poly);
+        n >>= 1;
+    }
+    return r;
+}
+
+/* ---------------- public ---------------- */
+
+orc_ac3enc_t *orc_ac3enc_init(int freq, int bitrate, int channels, int *frame_bytes)
+{
+    static const uint8_t acmod_of[6] = { 1, 2, 3, 6, 7, 7 };
+    static const uint16_t rates[3] = { 48000, 44100, 32000 };
+    static const uint16_t kbps[19] = { 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320,
+                                       384, 448, 512, 576, 640 };
+    orc_ac3enc_t *s;
+    int i, j, found = 0, ch;
+
+    if (frame_bytes) *frame_bytes = 0;
+    if (channels < 1 || channels > 6) return NULL;
+    s = (orc_ac3enc_t *)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->acmod = acmod_of[channels - 1];
+    s->lfe = channels == 6;
+    s->nch_all = channels;
+    s->nfbw = channels > 5 ? 5 : channels;
+    s->lfe_ch = s->lfe ? 5 : -1;
+    for (i = 0; i < 3 && !found; i++)                              /* ac3enc.cpp:1048-1058 */
+        for (j = 0; j < 3; j++)
+            if ((rates[j] >> i) == freq) { s->halfrate = i; s->fscod = j; found = 1; break; }
+    if (!found) { free(s); return NULL; }
+    s->bsid = 8 + s->halfrate;
+    bitrate /= 1000;
+    for (i = 0; i < 19; i++) if ((kbps[i] >> s->halfrate) == bitrate) break;
+    if (i == 19) { free(s); return NULL; }
+    s->frmsizecod = i << 1;
+    s->frame_words = (bitrate * 1000 * 1536) / (freq * 16);
+    for (ch = 0; ch < s->nfbw; ch++) { s->chbwcod[ch] = 50; s->nb_coefs[ch] = (50 + 12) * 3 + 37; }
+    if (s->lfe) s->nb_coefs[5] = 7;
+    s->csnroffst = 40;
+    enc_build_tables();
+    if (frame_bytes) *frame_bytes = s->frame_words * 2;
+    return s;
+}
+
+void orc_ac3enc_free(orc_ac3enc_t *s) { free(s); }
+
+int orc_ac3enc_frame(orc_ac3enc_t *s, uint8_t *dst, const int16_t *samples, const uint8_t *chmap)
+{
+    int ch, b, j, frame_bits = 0, fs = s->frame_words, fs58, n;
+    bitw w;
+    unsigned crc1, crc2, inv;
+
+    for (ch = 0; ch < s->nch_all; ch++) {
+        for (b = 0; b < NBLK; b++) {
+            int16_t in[512];
+            const int16_t *sp = samples + s->nch_all * 256 * b + chmap[ch];
+            int v, acc = 0;
+
+            memcpy(in, s->last[ch], 512);                          /* :1673-1683 */
+            for (j = 0; j < 256; j++, sp += s->nch_all) in[256 + j] = s->last[ch][j] = *sp;
+            for (j = 0; j < 256; j++) {                            /* window :1686-1693 */
+                in[j] = (int16_t)((in[j] * win_q15[j]) >> 15);
+                in[511 - j] = (int16_t)((in[511 - j] * win_q15[j]) >> 15);
+            }
+            for (j = 0; j < 512; j++) acc |= abs(in[j]);           /* block floating point :1697-1700 */
+            v = 14 - ilog2(acc);
+            if (v < 0) v = 0;
+            s->shift[b][ch] = (int8_t)(v - 9);
+            if (v > 0) for (j = 0; j < 512; j++) in[j] = (int16_t)(in[j] * (1 << v));
+
+            orc_ac3enc_mdct512(s->mdct[b][ch], in);
+
+            for (j = 0; j < 256; j++) {                            /* exponents :1707-1722 */
+                int e, a = abs(s->mdct[b][ch][j]);
+                if (a == 0) e = 24;
+                else {
+                    e = 23 - ilog2(a) + s->shift[b][ch];
+                    if (e >= 24) { e = 24; s->mdct[b][ch][j] = 0; }
+                }
+                s->expo[b][ch][j] = (uint8_t)e;
+            }
+        }
+        choose_strategies(s, ch);
+        for (b = 0; b < NBLK;) {                                   /* :1731-1749 */
+            int e = b + 1, k;
+            while (e < NBLK && s->strat[e][ch] == EXP_REUSE) {
+                for (j = 0; j < s->nb_coefs[ch]; j++)
+                    if (s->expo[e][ch][j] < s->expo[b][ch][j]) s->expo[b][ch][j] = s->expo[e][ch][j];
+                e++;
+            }
+            frame_bits += constrain_exponents(s->enc_exp[b][ch], s->expo[b][ch], s->nb_coefs[ch], s->strat[b][ch]);
+            for (k = b + 1; k < e; k++) memcpy(s->enc_exp[k][ch], s->enc_exp[b][ch], s->nb_coefs[ch]);
+            b = e;
+        }
+    }
+
+    search_allocation(s, frame_bits);
+
+    memset(dst, 0, fs * 2);
+    w.buf = dst; w.nbits = 0;
+    put(&w, 16, 0x0b77);                                           /* header :1113-1147 */
+    put(&w, 16, 0);
+    put(&w, 2, s->fscod);
+    put(&w, 6, s->frmsizecod);
+    put(&w, 5, s->bsid);
+    put(&w, 3, 0);
+    put(&w, 3, s->acmod);
+    if ((s->acmod & 1) && s->acmod != 1) put(&w, 2, 1);
+    if (s->acmod & 4) put(&w, 2, 1);
+    if (s->acmod == 2) put(&w, 2, 0);
+    put(&w, 1, s->lfe);
+    put(&w, 5, 31);
+    put(&w, 3, 0);
+    put(&w, 1, 0);
+    put(&w, 1, 1);
+    put(&w, 3, 0);
+    for (b = 0; b < NBLK; b++) {
+        /* never write past the frame: the reference would overrun here (its own
+         * note at ac3enc.cpp:1609-1613); such frames are out of contract */
+        if (w.nbits > (uint32_t)(fs * 16 - 16)) return -1;
+        write_block(s, &w, b);
+    }
+    n = (int)((w.nbits + 7) >> 3);
+    if (n > fs * 2 - 2) return -1;
+
+    fs58 = (fs >> 1) + (fs >> 3);                                  /* :1624-1635 */
+    crc1 = crc_run(dst + 4, 2 * fs58 - 4, 0);
+    inv = gf_pow(0x18005 >> 1, 16 * fs58 - 16, 0x18005);
+    crc1 = gf_mul(inv, crc1, 0x18005);
+    dst[2] = (uint8_t)(crc1 >> 8);
+    dst[3] = (uint8_t)crc1;
+    crc2 = crc_run(dst + 2 * fs58, (fs - fs58) * 2 - 2, 0);
+    dst[2 * fs - 2] = (uint8_t)(crc2 >> 8);
+    dst[2 * fs - 1] = (uint8_t)crc2;
+    return fs * 2;
+}
+
+void orc_ac3enc_get_mdct(orc_ac3enc_t *s, int32_t *dst) { memcpy(dst, s->mdct, sizeof s->mdct); }
+void orc_ac3enc_get_exp(orc_ac3enc_t *s, uint8_t *exponent, uint8_t *encoded)
+{
+    memcpy(exponent, s->expo, sizeof s->expo);
+    memcpy(encoded, s->enc_exp, sizeof s->enc_exp);
+}
+void orc_ac3enc_get_bap(orc_ac3enc_t *s, uint8_t *bap) { memcpy(bap, s->bap, sizeof s->bap); }
+void orc_ac3enc_get_misc(orc_ac3enc_t *s, uint8_t *strat, int8_t *shift, int *csnr, int *fsnr)
+{
+    memcpy(strat, s->strat, sizeof s->strat);
+    memcpy(shift, s->shift, sizeof s->shift);
+    *csnr = s->csnroffst;
+    *fsnr = s->fsnroffst;
+}
+
+int orc_ac3enc_encode_frames(int freq, int bitrate, int channels, const int16_t *pcm, int n,
+                             const uint8_t *chmap, uint8_t *out)
+{
+    int fb, f, bad = 0;
+    orc_ac3enc_t *s = orc_ac3enc_init(freq, bitrate, channels, &fb);
+    uint8_t tmp[3840];
+    if (!s) return -1;
+    for (f = 0; f < n; f++) {
+        uint8_t *dst = out ? out + (size_t)f * fb : tmp;
+        if (orc_ac3enc_frame(s, dst, pcm + (size_t)f * 1536 * channels, chmap) != fb) bad++;
+    }
+    orc_ac3enc_free(s);
+    return bad;
+}

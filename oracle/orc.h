@@ -1,0 +1,85 @@
+/* oracle/orc.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * C declarations of the CPU oracle (liborc.so): our own restatement of the
+ * reference's AC-3 decode path (liba52: parse.c, bit_allocate.c, imdct.c,
+ * downmix.c) and encode path (src/ac3enc/ac3enc.cpp).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the
+ * product (ac-3-acm-codec_amd/) never links or loads it.
+ *
+ * Pinning status:
+ *   decode  — pinned bit-for-bit against oracle/_ref/liba52_ref.so (the real
+ *             liba52 compiled from /root/reference) and the fixtures in
+ *             tests/golden/ generated from it.
+ *   encode  — PARITY UNPINNED: ac3enc.cpp needs <windows.h>/<crtdbg.h>, which
+ *             this image lacks, and the reference ships no encoder vectors.
+ *             Cross-checked only indirectly: the real liba52 decodes every
+ *             oracle-encoded frame without error and recovers the PCM.
+ */
+#ifndef ORC_H
+#define ORC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- decode (mirrors a52dec-0.7.5-cvs/include/a52.h:56-65) ---- */
+typedef struct orc_a52 orc_a52_t;
+
+orc_a52_t *orc_a52_init(void);
+float *orc_a52_samples(orc_a52_t *st);
+int orc_a52_syncinfo(const uint8_t *buf, int *flags, int *sample_rate, int *bit_rate);
+int orc_a52_frame(orc_a52_t *st, const uint8_t *buf, int *flags, float *level, float bias);
+void orc_a52_dynrng(orc_a52_t *st, float (*call)(float, void *), void *data);
+int orc_a52_block(orc_a52_t *st);
+void orc_a52_free(orc_a52_t *st);
+
+/* stage taps: which 0..4 = fbw channel, 5 = lfe, 6 = coupling channel */
+void orc_a52_get_exp(orc_a52_t *st, int which, uint8_t *dst256);
+void orc_a52_get_bap(orc_a52_t *st, int which, int8_t *dst256);
+int orc_a52_get_lfsr(orc_a52_t *st);
+void orc_a52_set_lfsr(orc_a52_t *st, int v);
+int orc_a52_get_output(orc_a52_t *st);
+long orc_a52_bitpos(orc_a52_t *st);
+
+/* transform-only entry points (liba52/a52_internal.h:106-120) */
+void orc_imdct_512(float *data, float *delay, float bias);
+void orc_imdct_256(float *data, float *delay, float bias);
+int orc_downmix_init(int input, int flags, float *level, float clev, float slev);
+int orc_downmix_coeff(float *coeff, int acmod, int output, float level, float clev, float slev);
+void orc_downmix(float *samples, int acmod, int output, float bias, float clev, float slev);
+void orc_upmix(float *samples, int acmod, int output);
+void orc_imdct_tables(float *window256, float *pre1_256, float *post1_128, float *pre2_128, float *post2_64);
+
+/* float(bias 384) -> s16 interleaved WAVE order (src/AC3ASM.asm, saturating/MMX flavour) */
+void orc_convert_s16(const float *planes, int16_t *dst, int flags);
+
+/* whole-stream helper used by bench.py's cpu_baseline: decodes n back-to-back
+ * frames of frame_bytes each into planar float (6 blocks x nch x 256 per frame) */
+int orc_a52_decode_frames(const uint8_t *frames, int n, int frame_bytes, int flags,
+                          float level, float bias, float *pcm_or_null);
+
+/* ---- encode (mirrors src/ac3enc/ac3enc.h:6-7, but re-entrant) ---- */
+typedef struct orc_ac3enc orc_ac3enc_t;
+
+orc_ac3enc_t *orc_ac3enc_init(int freq, int bitrate, int channels, int *frame_bytes);
+int orc_ac3enc_frame(orc_ac3enc_t *s, uint8_t *dst, const int16_t *samples, const uint8_t *chmap);
+void orc_ac3enc_free(orc_ac3enc_t *s);
+
+/* stage taps of the last encoded frame */
+void orc_ac3enc_get_mdct(orc_ac3enc_t *s, int32_t *dst /*[6][6][256]*/);
+void orc_ac3enc_get_exp(orc_ac3enc_t *s, uint8_t *exponent, uint8_t *encoded_exp /*[6][6][256] each*/);
+void orc_ac3enc_get_bap(orc_ac3enc_t *s, uint8_t *bap /*[6][6][256]*/);
+void orc_ac3enc_get_misc(orc_ac3enc_t *s, uint8_t *exp_strategy /*[6][6]*/, int8_t *exp_samples /*[6][6]*/,
+                         int *csnroffst, int *fsnroffst);
+void orc_ac3enc_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128,
+                       uint16_t *crc256);
+void orc_ac3enc_mdct512(int32_t *out256, const int16_t *in512);
+int orc_ac3enc_encode_frames(int freq, int bitrate, int channels, const int16_t *pcm, int n,
+                             const uint8_t *chmap, uint8_t *out_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
