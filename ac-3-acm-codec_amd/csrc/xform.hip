@@ -1,0 +1,233 @@
+// xform.hip — batched AC-3 synthesis transform for gfx950 (config 2 and config 4 of
+// BASELINE.json): IMDCT-512 / IMDCT-256 + KBD window + overlap-add, with the
+// liba52 downmix folded in.  Replaces L52/imdct.c:258-345 + L52/downmix.c:480-619 +
+// the dispatch at L52/parse.c:881-937.
+//
+// Work decomposition: one "chain" = one OUTPUT channel of one stream, walked
+// sequentially through its frames x 6 blocks because each block's tail is the next
+// block's overlap.  A chain is executed by an 8-lane group (xform_core.h); a
+// wavefront carries 8 chains, a 256-thread workgroup 32.  The 128-float overlap
+// tail lives in registers for the whole walk and touches HBM once per call.
+//
+// HBM traffic per channel-block: 1 KiB coefficients in (x number of mixed input
+// planes), 1 KiB PCM out; all accesses are 8 B per lane, 64 B contiguous per group.
+// LDS: one 8x16 complex transpose per transform (1216 B per group, padded rows).
+#include "ac3mi_internal.h"
+#include "xform_core.h"
+
+namespace ac3mi {
+
+struct XformParams {
+    const float *coef;
+    const uint8_t *blksw;
+    float *delay;
+    float *pcm;
+    const float2 *tw_long;
+    const float2 *tw_short;
+    const float *window;
+    int n_chains;
+    int frames;
+    int n_in, n_out, nfchans, in_lfe;
+    float bias;
+    int8_t mix[6][6];
+};
+
+// long-block input pattern: lane l8 owns m = 8*n1 + l8
+__device__ __forceinline__ void load_long(const float *plane, int l8, float sign, float (&xa)[16], float (&xb)[16])
+{
+    const float2 *p = reinterpret_cast<const float2 *>(plane) + l8;
+    float2 v[16];
+#pragma unroll
+    for (int n = 0; n < 16; n++) v[n] = p[8 * n];
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        xa[n] += sign * v[n].x;                     // X[2m]
+        xb[n] += sign * mirror8(v[15 - n].y);       // X[255-2m] = X[2m'+1], m' = 127-m
+    }
+}
+
+// short-block input pattern: lane l8 = 4f + n2
+__device__ __forceinline__ void load_short(const float *plane, int l8, float sign, float (&xa)[16], float (&xb)[16])
+{
+    const int f = l8 >> 2, n2 = l8 & 3;
+    const float *pa = plane + 4 * n2 + f;
+    const float *pb = plane + 254 + f - 4 * n2;
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+        xa[n] += sign * pa[16 * n];
+        xb[n] += sign * pb[-16 * n];
+    }
+}
+
+template <bool MIX>
+__global__ __launch_bounds__(256) void xform_kernel(const XformParams P)
+{
+    __shared__ float2 lds_ex[4 * EX_WAVE];
+
+    const int tid = threadIdx.x;
+    const int l8 = tid & 7;
+    const int group = tid >> 3;                     // 0..31 inside the workgroup
+    const int chain = blockIdx.x * 32 + group;
+    if (chain >= P.n_chains) return;                // whole 8-lane groups leave together
+    float2 *ex = lds_ex + group * EX_GROUP;
+
+    const int s = chain / P.n_out;
+    const int o = chain - s * P.n_out;
+
+    // lane constants
+    cf twl[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        float2 t = P.tw_long[l8 * 16 + k];
+        twl[k] = {t.x, t.y};
+    }
+    // window taps of the 8 owned i: w[2i], w[2i+1], w[254-2i], w[255-2i]
+    float2 wlo[8], whi[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+        wlo[j] = *reinterpret_cast<const float2 *>(P.window + 2 * i);
+        whi[j] = *reinterpret_cast<const float2 *>(P.window + 254 - 2 * i);
+    }
+    // overlap tail of this chain
+    float2 dl[8];
+    float *dptr = P.delay + (size_t)chain * 128;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+        dl[j] = *reinterpret_cast<const float2 *>(dptr + 2 * i);
+    }
+
+    const size_t in_stride_blk = (size_t)P.n_in * 256;
+    const size_t out_stride_blk = (size_t)P.n_out * 256;
+    const float *cbase = P.coef + (size_t)s * P.frames * 6 * in_stride_blk;
+    float *obase = P.pcm + (size_t)s * P.frames * 6 * out_stride_blk + (size_t)o * 256;
+    const uint8_t *swbase = P.blksw ? P.blksw + (size_t)s * P.frames * 6 * P.nfchans : nullptr;
+
+    const int nblk = P.frames * 6;
+    for (int b = 0; b < nblk; b++) {
+        const float *cblk = cbase + (size_t)b * in_stride_blk;
+        FirstTail ft;
+#pragma unroll
+        for (int j = 0; j < 8; j++) ft.f0[j] = ft.f1[j] = ft.t0[j] = ft.t1[j] = 0.f;
+
+        if (!MIX) {
+            // identity routing: input plane index == output plane index
+            const int fb = o - P.in_lfe;
+            const int sw = (swbase && fb >= 0) ? swbase[(size_t)b * P.nfchans + fb] : 0;
+            float xa[16], xb[16];
+#pragma unroll
+            for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
+            if (!sw) {
+                load_long(cblk + (size_t)o * 256, l8, 1.f, xa, xb);
+                imdct_long(xa, xb, twl, ex, l8, ft);
+            } else {
+                cf tws[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    float2 t = P.tw_short[l8 * 16 + k];
+                    tws[k] = {t.x, t.y};
+                }
+                load_short(cblk + (size_t)o * 256, l8, 1.f, xa, xb);
+                imdct_short(xa, xb, tws, ex, l8, ft);
+            }
+        } else {
+            // sum the long-block inputs and the short-block inputs of this output
+            // separately (the transforms are linear), at most one transform of each kind
+            float xa[16], xb[16];
+            bool any;
+#pragma unroll
+            for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
+            any = false;
+            for (int c = 0; c < P.n_in; c++) {
+                const int m = P.mix[o][c];
+                if (!m) continue;
+                const int fb = c - P.in_lfe;
+                const int sw = (swbase && fb >= 0) ? swbase[(size_t)b * P.nfchans + fb] : 0;
+                if (sw) continue;
+                load_long(cblk + (size_t)c * 256, l8, (float)m, xa, xb);
+                any = true;
+            }
+            if (any) imdct_long(xa, xb, twl, ex, l8, ft);
+            if (swbase) {
+#pragma unroll
+                for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
+                any = false;
+                for (int c = 0; c < P.n_in; c++) {
+                    const int m = P.mix[o][c];
+                    if (!m) continue;
+                    const int fb = c - P.in_lfe;
+                    const int sw = (fb >= 0) ? swbase[(size_t)b * P.nfchans + fb] : 0;
+                    if (!sw) continue;
+                    load_short(cblk + (size_t)c * 256, l8, (float)m, xa, xb);
+                    any = true;
+                }
+                if (any) {
+                    cf tws[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        float2 t = P.tw_short[l8 * 16 + k];
+                        tws[k] = {t.x, t.y};
+                    }
+                    imdct_short(xa, xb, tws, ex, l8, ft);
+                }
+            }
+        }
+
+        // window + overlap-add + bias, then the new tail
+        float *oblk = obase + (size_t)b * out_stride_blk;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+            float2 lo, hi;
+            lo.x = ft.f0[j] * wlo[j].x + (dl[j].x * whi[j].y + P.bias);    // out[2i]
+            lo.y = ft.f1[j] * wlo[j].y + (dl[j].y * whi[j].x + P.bias);    // out[2i+1]
+            hi.x = dl[j].y * wlo[j].y + P.bias - ft.f1[j] * whi[j].x;      // out[254-2i]
+            hi.y = dl[j].x * wlo[j].x + P.bias - ft.f0[j] * whi[j].y;      // out[255-2i]
+            *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
+            *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
+            dl[j].x = ft.t0[j];
+            dl[j].y = ft.t1[j];
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+        *reinterpret_cast<float2 *>(dptr + 2 * i) = dl[j];
+    }
+}
+
+hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream_t stream)
+{
+    XformParams P;
+    P.coef = L.coef;
+    P.blksw = L.blksw;
+    P.delay = L.delay;
+    P.pcm = L.pcm;
+    P.tw_long = tab.tw_long;
+    P.tw_short = tab.tw_short;
+    P.window = tab.window;
+    P.n_chains = L.n_streams * L.plan.n_out;
+    P.frames = L.frames;
+    P.n_in = L.plan.n_in;
+    P.n_out = L.plan.n_out;
+    P.nfchans = L.plan.nfchans;
+    P.in_lfe = L.plan.in_lfe;
+    P.bias = L.bias;
+    bool identity = (L.plan.n_in == L.plan.n_out);
+    for (int o = 0; o < 6; o++)
+        for (int c = 0; c < 6; c++) {
+            P.mix[o][c] = L.plan.mix[o][c];
+            if (o < L.plan.n_out && c < L.plan.n_in && L.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
+        }
+    if (P.n_chains <= 0 || P.frames <= 0) return hipSuccess;
+    const int grid = (P.n_chains + 31) / 32;
+    if (identity)
+        hipLaunchKernelGGL(xform_kernel<false>, dim3(grid), dim3(256), 0, stream, P);
+    else
+        hipLaunchKernelGGL(xform_kernel<true>, dim3(grid), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace ac3mi

@@ -1,0 +1,94 @@
+"""Host-side mirror of the batched engine: torch tensors in, torch tensors out.
+
+torch is plumbing here (device memory + dtype checks); every computation happens
+in libac3mi.so.  Mirrors the stage boundaries of the reference:
+``Engine.imdct_batch`` = the synthesis stage of a52_block (liba52/parse.c:881-937).
+"""
+import ctypes
+from dataclasses import dataclass
+
+from . import capi
+
+
+@dataclass
+class XformDesc:
+    acmod: int = 7
+    lfeon: int = 1
+    output: int = 7 | 16
+    bias: float = 0.0
+
+    def c(self):
+        return capi.XformDescC(self.acmod, self.lfeon, self.output, self.bias)
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = capi.load_library()
+        self.ctx = self.lib.ac3mi_create(device)
+        if not self.ctx:
+            raise capi.AC3MIError(self.lib.ac3mi_last_error(None).decode())
+        self.device = device
+        # tensors handed to in-flight launches: torch's caching allocator only orders reuse on
+        # torch's own stream, so keep them alive until the engine stream has been drained
+        self._keep = []
+
+    def close(self):
+        if self.ctx:
+            self.lib.ac3mi_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise capi.AC3MIError("ac3mi error %d: %s" % (rc, self.lib.ac3mi_last_error(self.ctx).decode()))
+
+    def sync(self):
+        self._check(self.lib.ac3mi_sync(self.ctx))
+        self._keep.clear()
+
+    def timer_start(self):
+        self._check(self.lib.ac3mi_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._check(self.lib.ac3mi_timer_stop(self.ctx, ctypes.byref(ms)))
+        self._keep.clear()
+        return ms.value
+
+    def planes(self, desc):
+        n_in, n_out = ctypes.c_int(), ctypes.c_int()
+        c = desc.c()
+        rc = self.lib.ac3mi_xform_planes(ctypes.byref(c), ctypes.byref(n_in), ctypes.byref(n_out))
+        if rc != 0:
+            raise capi.AC3MIError("output flags %d not reachable from acmod %d" % (desc.output, desc.acmod))
+        return n_in.value, n_out.value
+
+    def imdct_batch(self, desc, coeffs, delay, blksw=None, out=None, wait_torch=True):
+        """coeffs [S][F][6][n_in][256] f32, delay [S][n_out][128] f32 (updated in place),
+        blksw None or [S][F][6][nfchans] u8  ->  pcm [S][F][6][n_out][256] f32.
+
+        The engine runs on its own HIP stream: with wait_torch the call first drains torch's
+        stream (the inputs were produced there); call sync() before reading the result."""
+        import torch
+        if wait_torch:
+            torch.cuda.synchronize(self.device)
+        n_in, n_out = self.planes(desc)
+        S, F = coeffs.shape[0], coeffs.shape[1]
+        assert coeffs.dtype == torch.float32 and coeffs.is_contiguous() and coeffs.is_cuda
+        assert tuple(coeffs.shape) == (S, F, 6, n_in, 256), coeffs.shape
+        assert delay.dtype == torch.float32 and delay.is_contiguous() and tuple(delay.shape) == (S, n_out, 128)
+        if blksw is not None:
+            assert blksw.dtype == torch.uint8 and blksw.is_contiguous() and blksw.shape[:3] == (S, F, 6)
+        if out is None:
+            out = torch.empty((S, F, 6, n_out, 256), dtype=torch.float32, device=coeffs.device)
+        c = desc.c()
+        self._check(self.lib.ac3mi_imdct_batch(self.ctx, ctypes.byref(c), coeffs.data_ptr(),
+                                               blksw.data_ptr() if blksw is not None else None,
+                                               delay.data_ptr(), out.data_ptr(), S, F))
+        self._keep.append((coeffs, delay, blksw, out))
+        return out

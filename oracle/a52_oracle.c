@@ -1310,6 +1310,91 @@ static void unpack_coupling(orc_a52_t *st, int nfchans, const float *gain, float
     }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* synthesis stage of a block: parse.c:881-937.  `s` points at the first fbw
+ * plane (LFE, when output, sits at s-256 and has been transformed already);
+ * overlap planes live 1536 floats further on. */
+static void synth_stage(float *s, int *downmixed, int acmod, int output, float bias, float clev, float slev,
+                        const uint8_t *blksw, const float *gain, int biasmask)
+{
+    int nf = nfchans_of[acmod], i, j;
+
+    i = 0;
+    if (nfchans_of[output & CH_MASK] < nf)
+        for (i = 1; i < nf; i++)
+            if (blksw[i] != blksw[0]) break;
+
+    if (i < nf) {
+        /* path A: block sizes differ -> transform every coded channel, mix in time domain */
+        if (*downmixed) {
+            *downmixed = 0;
+            orc_upmix(s + 1536, acmod, output);
+        }
+        for (i = 0; i < nf; i++) {
+            float b = (biasmask & (1 << i)) ? 0 : bias;
+            if (gain[i]) {
+                if (blksw[i]) orc_imdct_256(s + 256 * i, s + 1536 + 256 * i, b);
+                else orc_imdct_512(s + 256 * i, s + 1536 + 256 * i, b);
+            } else
+                for (j = 0; j < 256; j++) s[256 * i + j] = b;
+        }
+        orc_downmix(s, acmod, output, bias, clev, slev);
+    } else {
+        /* path B: mix coefficients first, transform only the output channels */
+        int nout = nfchans_of[output & CH_MASK];
+        orc_downmix(s, acmod, output, 0, clev, slev);
+        if (!*downmixed) {
+            *downmixed = 1;
+            orc_downmix(s + 1536, acmod, output, 0, clev, slev);
+        }
+        for (i = 0; i < nout; i++) {
+            if (blksw[0]) orc_imdct_256(s + 256 * i, s + 1536 + 256 * i, bias);
+            else orc_imdct_512(s + 256 * i, s + 1536 + 256 * i, bias);
+        }
+    }
+}
+
+/* Transform-only oracle for BASELINE configs 2 and 4: runs the synthesis stage of
+ * a52_block (LFE transform parse.c:867-873 + synth_stage) over coefficient planes
+ * laid out like the product's ac3mi_imdct_batch: coef [S][F][6][n_in][256] with the
+ * LFE plane first when lfeon, blksw NULL or [S][F][6][nfchans], pcm
+ * [S][F][6][n_out][256].  state: per stream 12*256 floats (liba52's sample
+ * buffer, planes 6-11 = overlap) + downmixed flag, both carried across calls. */
+int orc_xform_batch(const float *coef, const uint8_t *blksw, float *state_planes, int *state_downmixed,
+                    float *pcm, int n_streams, int frames, int acmod, int lfeon, int output, float bias,
+                    float clev, float slev)
+{
+    static const uint8_t zero_sw[5] = { 0, 0, 0, 0, 0 };
+    int nf, nout_f, n_in, n_out, out_lfe, biasmask;
+    float gain[5];
+    if (acmod < 0 || acmod > 7 || (output & CH_MASK) > CH_DOLBY) return -1;
+    build_tables();
+    nf = nfchans_of[acmod];
+    nout_f = nfchans_of[output & CH_MASK];
+    out_lfe = (output & F_LFE) ? 1 : 0;
+    n_in = nf + (lfeon ? 1 : 0);
+    n_out = nout_f + out_lfe;
+    biasmask = orc_downmix_coeff(gain, acmod, output, 1.0f, clev, slev);
+    for (int i = 0; i < 5; i++) gain[i] = 1.0f;     /* transform-only: every plane is live */
+    for (int st = 0; st < n_streams; st++) {
+        float *planes = state_planes + (size_t)st * 3072;
+        float *s = planes + (out_lfe ? 256 : 0);
+        for (int fb = 0; fb < frames * 6; fb++) {
+            const float *c = coef + ((size_t)st * frames * 6 + fb) * n_in * 256;
+            const uint8_t *sw = blksw ? blksw + ((size_t)st * frames * 6 + fb) * nf : zero_sw;
+            if (lfeon && out_lfe) {
+                memcpy(s - 256, c, 256 * sizeof(float));
+                orc_imdct_512(s - 256, s + 1536 - 256, bias);
+            }
+            memcpy(s, c + (lfeon ? 256 : 0), (size_t)nf * 256 * sizeof(float));
+            synth_stage(s, &state_downmixed[st], acmod, output, bias, clev, slev, sw, gain, biasmask);
+            memcpy(pcm + ((size_t)st * frames * 6 + fb) * n_out * 256, planes, (size_t)n_out * 256 * sizeof(float));
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* one audio block: parse.c:558-940                                    */
 
@@ -1522,39 +1607,7 @@ int orc_a52_block(orc_a52_t *st)
     }
 
     /* ---- synthesis (parse.c:881-937) ---- */
-    i = 0;
-    if (nfchans_of[st->output & CH_MASK] < nf)
-        for (i = 1; i < nf; i++)
-            if (blksw[i] != blksw[0]) break;
-
-    if (i < nf) {
-        /* path A: block sizes differ -> transform every coded channel, mix in time domain */
-        if (st->downmixed) {
-            st->downmixed = 0;
-            orc_upmix(s + 1536, st->acmod, st->output);
-        }
-        for (i = 0; i < nf; i++) {
-            float b = (biasmask & (1 << i)) ? 0 : st->bias;
-            if (gain[i]) {
-                if (blksw[i]) orc_imdct_256(s + 256 * i, s + 1536 + 256 * i, b);
-                else orc_imdct_512(s + 256 * i, s + 1536 + 256 * i, b);
-            } else
-                for (j = 0; j < 256; j++) s[256 * i + j] = b;
-        }
-        orc_downmix(s, st->acmod, st->output, st->bias, st->clev, st->slev);
-    } else {
-        /* path B: mix coefficients first, transform only the output channels */
-        int nout = nfchans_of[st->output & CH_MASK];
-        orc_downmix(s, st->acmod, st->output, 0, st->clev, st->slev);
-        if (!st->downmixed) {
-            st->downmixed = 1;
-            orc_downmix(s + 1536, st->acmod, st->output, 0, st->clev, st->slev);
-        }
-        for (i = 0; i < nout; i++) {
-            if (blksw[0]) orc_imdct_256(s + 256 * i, s + 1536 + 256 * i, st->bias);
-            else orc_imdct_512(s + 256 * i, s + 1536 + 256 * i, st->bias);
-        }
-    }
+    synth_stage(s, &st->downmixed, st->acmod, st->output, st->bias, st->clev, st->slev, blksw, gain, biasmask);
     return 0;
 }
 

@@ -52,6 +52,12 @@ void orc_downmix(float *samples, int acmod, int output, float bias, float clev, 
 void orc_upmix(float *samples, int acmod, int output);
 void orc_imdct_tables(float *window256, float *pre1_256, float *post1_128, float *pre2_128, float *post2_64);
 
+/* transform-only oracle (BASELINE configs 2 and 4), layouts as ac3mi_imdct_batch;
+ * state_planes [S][12*256] (liba52 sample buffer incl. overlap planes), state_downmixed [S] */
+int orc_xform_batch(const float *coef, const uint8_t *blksw, float *state_planes, int *state_downmixed,
+                    float *pcm, int n_streams, int frames, int acmod, int lfeon, int output, float bias,
+                    float clev, float slev);
+
 /* float(bias 384) -> s16 interleaved WAVE order (src/AC3ASM.asm, saturating/MMX flavour) */
 void orc_convert_s16(const float *planes, int16_t *dst, int flags);
 

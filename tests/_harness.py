@@ -1,0 +1,239 @@
+"""Shared test plumbing: package import, oracle (liborc.so) and reference-build
+(oracle/_ref/liba52_ref.so) bindings, seeded synthetic inputs.
+
+The oracle is TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg import this module.
+"""
+import ctypes
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORC_PATH = os.path.join(ORACLE_DIR, "liborc.so")
+REF_PATH = os.path.join(ORACLE_DIR, "_ref", "liba52_ref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+i8p = ctypes.POINTER(ctypes.c_int8)
+i16p = ctypes.POINTER(ctypes.c_int16)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+i32p = ctypes.POINTER(ctypes.c_int32)
+fp = ctypes.POINTER(ctypes.c_float)
+ip = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+cf = ctypes.c_float
+
+NFCHANS = (2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2)
+CHMAP6 = (0, 2, 1, 4, 5, 3, 0, 0)      # create_channel_map, src/AC3ACM.cpp:1631-1662 (6-ch WAVE order)
+
+
+def pkg():
+    return importlib.import_module("ac-3-acm-codec_amd")
+
+
+def P(a, t):
+    return a.ctypes.data_as(t)
+
+
+_orc = None
+_ref = None
+
+
+def build_oracle():
+    if not os.path.exists(ORC_PATH) or os.path.getmtime(ORC_PATH) < max(
+            os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("a52_oracle.c", "ac3enc_oracle.c", "orc.h")):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "liborc.so")])
+
+
+def orc():
+    global _orc
+    if _orc is not None:
+        return _orc
+    build_oracle()
+    L = ctypes.CDLL(ORC_PATH)
+    L.orc_a52_init.restype = vp
+    L.orc_a52_samples.restype = fp
+    L.orc_a52_samples.argtypes = [vp]
+    L.orc_a52_syncinfo.argtypes = [u8p, ip, ip, ip]
+    L.orc_a52_frame.argtypes = [vp, u8p, ip, fp, cf]
+    L.orc_a52_block.argtypes = [vp]
+    L.orc_a52_free.argtypes = [vp]
+    L.orc_a52_free.restype = None
+    L.orc_a52_dynrng.argtypes = [vp, vp, vp]
+    L.orc_a52_get_exp.argtypes = [vp, ci, u8p]
+    L.orc_a52_get_bap.argtypes = [vp, ci, i8p]
+    L.orc_a52_get_lfsr.argtypes = [vp]
+    L.orc_a52_set_lfsr.argtypes = [vp, ci]
+    L.orc_a52_bitpos.argtypes = [vp]
+    L.orc_a52_bitpos.restype = ctypes.c_long
+    L.orc_imdct_512.argtypes = [fp, fp, cf]
+    L.orc_imdct_256.argtypes = [fp, fp, cf]
+    L.orc_imdct_tables.argtypes = [fp] * 5
+    L.orc_downmix_init.argtypes = [ci, ci, fp, cf, cf]
+    L.orc_downmix_coeff.argtypes = [fp, ci, ci, cf, cf, cf]
+    L.orc_downmix.argtypes = [fp, ci, ci, cf, cf, cf]
+    L.orc_upmix.argtypes = [fp, ci, ci]
+    L.orc_xform_batch.argtypes = [fp, u8p, fp, ip, fp, ci, ci, ci, ci, ci, cf, cf, cf]
+    L.orc_convert_s16.argtypes = [fp, i16p, ci]
+    L.orc_a52_decode_frames.argtypes = [u8p, ci, ci, ci, cf, cf, fp]
+    L.orc_ac3enc_init.restype = vp
+    L.orc_ac3enc_init.argtypes = [ci, ci, ci, ip]
+    L.orc_ac3enc_frame.argtypes = [vp, u8p, i16p, u8p]
+    L.orc_ac3enc_free.argtypes = [vp]
+    L.orc_ac3enc_free.restype = None
+    L.orc_ac3enc_get_mdct.argtypes = [vp, i32p]
+    L.orc_ac3enc_get_exp.argtypes = [vp, u8p, u8p]
+    L.orc_ac3enc_get_bap.argtypes = [vp, u8p]
+    L.orc_ac3enc_get_misc.argtypes = [vp, u8p, i8p, ip, ip]
+    L.orc_ac3enc_tables.argtypes = [i16p, i16p, i16p, i16p, u16p]
+    L.orc_ac3enc_mdct512.argtypes = [i32p, i16p]
+    L.orc_ac3enc_encode_frames.argtypes = [ci, ci, ci, i16p, ci, u8p, u8p]
+    _orc = L
+    return L
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def ref():
+    """The real liba52 built from /root/reference by oracle/Makefile (this container,
+    or the prebuilt binary shipped to the GPU box)."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    L = ctypes.CDLL(REF_PATH)
+    L.a52_init.restype = vp
+    L.a52_init.argtypes = [ctypes.c_uint32]
+    L.a52_samples.restype = fp
+    L.a52_samples.argtypes = [vp]
+    L.a52_syncinfo.argtypes = [u8p, ip, ip, ip]
+    L.a52_frame.argtypes = [vp, u8p, ip, fp, cf]
+    L.a52_block.argtypes = [vp]
+    L.a52_dynrng.argtypes = [vp, vp, vp]
+    L.a52_free.argtypes = [vp]
+    L.a52_free.restype = None
+    L.a52_imdct_init.argtypes = [ctypes.c_uint32]
+    L.a52_imdct_512.argtypes = [fp, fp, cf]
+    L.a52_imdct_256.argtypes = [fp, fp, cf]
+    L.a52_downmix_init.argtypes = [ci, ci, fp, cf, cf]
+    L.a52_downmix_coeff.argtypes = [fp, ci, ci, cf, cf, cf]
+    L.a52_downmix.argtypes = [fp, ci, ci, cf, cf, cf]
+    L.a52_upmix.argtypes = [fp, ci, ci]
+    L.refglue_get_exp.argtypes = [vp, ci, u8p]
+    L.refglue_get_bap.argtypes = [vp, ci, i8p]
+    L.refglue_get_lfsr.argtypes = [vp]
+    L.refglue_bitpos.argtypes = [vp, u8p]
+    L.refglue_bitpos.restype = ctypes.c_long
+    L.convert2s16_multi.argtypes = [fp, i16p, ci]
+    L.convert2s16_2.argtypes = [fp, i16p]
+    L.a52_imdct_init(0)
+    _ref = L
+    return L
+
+
+# ---------------------------------------------------------------------------
+# synthetic inputs
+
+def gen_pcm(nframes, nch=6, seed=12345, kind="tones"):
+    """s16 interleaved WAVE-order PCM, 1536*nframes samples per channel.
+
+    tones : per channel a sine (amp 8000, phase step 0.01*(c+1) + slow chirp) + uniform noise +-2048
+    noise : full-scale white noise (stresses bit allocation, many new-exponent blocks)
+    quiet : digital silence with an occasional +-1 (exp 24, zero bap, dither path)
+    music : a few in-band partials per channel, low noise (codes well: SNR check)
+    """
+    n = nframes * 1536
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64)
+    out = np.zeros((n, nch), np.float64)
+    for c in range(nch):
+        if kind == "tones":
+            out[:, c] = 8000 * np.sin(0.01 * (c + 1) * t + 1e-7 * (c + 1) * t * t) + rng.integers(-2048, 2049, n)
+        elif kind == "noise":
+            out[:, c] = rng.integers(-30000, 30001, n)
+        elif kind == "quiet":
+            out[:, c] = (rng.random(n) < 0.001) * rng.integers(-1, 2, n)
+        elif kind == "music":
+            for k in range(4):
+                out[:, c] += 2500 * np.sin(2 * np.pi * (110.0 * (c + 1) * (k + 1) / 48000.0) * t + k)
+            out[:, c] += rng.integers(-8, 9, n)
+        else:
+            raise ValueError(kind)
+    return np.clip(np.round(out), -32768, 32767).astype(np.int16)
+
+
+def orc_encode(pcm, nch=6, bitrate=384000, freq=48000, chmap=CHMAP6):
+    """Encode interleaved s16 PCM as one stream with the encoder oracle -> [nframes][frame_bytes] u8."""
+    L = orc()
+    nframes = pcm.shape[0] // 1536
+    fb = ci()
+    h = L.orc_ac3enc_init(freq, bitrate, nch, ctypes.byref(fb))
+    assert h, "orc_ac3enc_init rejected %d/%d/%d" % (freq, bitrate, nch)
+    out = np.zeros((nframes, fb.value), np.uint8)
+    cm = (ctypes.c_uint8 * 8)(*chmap)
+    pcm = np.ascontiguousarray(pcm)
+    for f in range(nframes):
+        r = L.orc_ac3enc_frame(h, P(out[f], u8p), ctypes.cast(pcm.ctypes.data + f * 1536 * nch * 2, i16p), cm)
+        assert r == fb.value, "oracle encoder failed on frame %d" % f
+    L.orc_ac3enc_free(h)
+    return out
+
+
+def _decode_stream(L, prefix, frames, flags, level, bias, dynrng_off=False, taps=False):
+    init = getattr(L, prefix + "init")
+    st = init() if prefix == "orc_a52_" else init(0)
+    nfr, fb = frames.shape
+    buf = np.zeros(nfr * fb + 64, np.uint8)
+    buf[:nfr * fb] = frames.reshape(-1)
+    pcm, errs, outflags = [], 0, flags
+    for f in range(nfr):
+        fl, lv = ci(flags), cf(level)
+        p = ctypes.cast(buf.ctypes.data + f * fb, u8p)
+        errs += getattr(L, prefix + "frame")(st, p, ctypes.byref(fl), ctypes.byref(lv), bias)
+        if dynrng_off:
+            getattr(L, prefix + "dynrng")(st, None, None)
+        outflags = fl.value
+        nout = NFCHANS[outflags & 15] + (1 if outflags & 16 else 0)
+        for b in range(6):
+            errs += getattr(L, prefix + "block")(st)
+            pcm.append(np.ctypeslib.as_array(getattr(L, prefix + "samples")(st), (1536,))[:nout * 256].copy())
+    getattr(L, prefix + "free")(st)
+    nout = NFCHANS[outflags & 15] + (1 if outflags & 16 else 0)
+    return np.array(pcm, np.float32).reshape(nfr, 6, nout, 256), errs, outflags
+
+
+def orc_decode(frames, flags=7 | 16, level=1.0, bias=0.0, dynrng_off=False):
+    return _decode_stream(orc(), "orc_a52_", frames, flags, level, bias, dynrng_off)
+
+
+def ref_decode(frames, flags=7 | 16, level=1.0, bias=0.0, dynrng_off=False):
+    return _decode_stream(ref(), "a52_", frames, flags, level, bias, dynrng_off)
+
+
+def orc_xform(coef, blksw, acmod, lfeon, output, bias=0.0, clev=0.0, slev=0.0, state=None):
+    """Transform-only oracle.  coef [S][F][6][n_in][256] -> pcm [S][F][6][n_out][256];
+    returns (pcm, (planes, downmixed)) with the liba52-style carry-over state."""
+    L = orc()
+    S, F = coef.shape[:2]
+    n_out = NFCHANS[output & 15] + (1 if output & 16 else 0)
+    if state is None:
+        state = (np.zeros((S, 3072), np.float32), np.ones(S, np.int32))
+    planes, dm = state
+    pcm = np.zeros((S, F, 6, n_out, 256), np.float32)
+    coef = np.ascontiguousarray(coef, np.float32)
+    sw = None if blksw is None else np.ascontiguousarray(blksw, np.uint8)
+    r = L.orc_xform_batch(P(coef, fp), P(sw, u8p) if sw is not None else None, P(planes, fp), P(dm, ip),
+                          P(pcm, fp), S, F, acmod, lfeon, output, bias, clev, slev)
+    assert r == 0
+    return pcm, (planes, dm)
+
+
+def rms(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt(np.mean(a * a))) if a.size else 0.0
