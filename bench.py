@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X AC-3 block-transform engine.
+
+Workload (BASELINE.json configs[1]): batched decode transform — 65536 independent
+5.1 / 48 kHz frames per GPU, each 6 blocks x 6 channels of 256 dequantised coefficients,
+through IMDCT-512 + KBD window + overlap-add (the synthesis stage of a52_block).
+One "step" = one pass of ac3mi_imdct_batch over that batch, inputs resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`; every rank owns
+   its own 65536 streams - independent streams shard with no data-path collective: weak scaling)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FRAMES_PER_GPU = 65536
+N_CH = 6
+# algorithmic HBM bytes per frame of this workload:
+# 36 planes x 1 KiB coefficients in + 36 x 1 KiB PCM out + 6 ch x 128 floats overlap state r+w
+BYTES_PER_FRAME = 36 * 1024 + 36 * 1024 + 2 * N_CH * 128 * 4
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The reference's CPU path for the same workload, on the host cores of this box.
+
+    kind "reference": liba52's own a52_imdct_512 (oracle/_ref/liba52_ref.so, compiled from the
+    reference sources in the build container) driven by a C loop; kind "port": oracle/liborc.so
+    when the reference build is absent.  Bounded sample, one worker thread per host core."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import _harness as H
+
+    # a 1-GPU box grants this job 16 host cores whatever the affinity mask says
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    frames_per_call = 512
+    rng = np.random.default_rng(1)
+    coef = (rng.standard_normal((frames_per_call, 6, N_CH, 256)) * 0.05).astype(np.float32)
+
+    if H.have_ref():
+        kind = "reference"
+        L = H.ref()
+        L.refglue_imdct512_batch.argtypes = [H.fp, H.fp, ctypes.c_long, ctypes.c_long, H.cf]
+        L.refglue_imdct512_batch.restype = None
+
+        def work(_):
+            data = coef.copy()
+            delay = np.zeros((N_CH, 256), np.float32)
+            # plane order [frame][blk][ch]: plane k belongs to chain k % 6 -> block-sequential per channel
+            L.refglue_imdct512_batch(H.P(data, H.fp), H.P(delay, H.fp), frames_per_call * 36, N_CH, 0.0)
+            return frames_per_call
+    else:
+        kind = "port"
+        H.orc()
+
+        def work(_):
+            H.orc_xform(coef.reshape(1, frames_per_call, 6, N_CH, 256), None, 7, 1, 7 | 16)
+            return frames_per_call
+
+    work(0)                                            # warm caches / page in
+    t0 = time.perf_counter()
+    work(0)
+    per_call = time.perf_counter() - t0
+    calls_per_thread = max(1, min(int(seconds_target / max(per_call, 1e-6)), 2000))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        done = sum(ex.map(work, range(cores * calls_per_thread)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d frames (36 x a52_imdct_512 each) on %d threads, %.1f s wall; 1-thread rate %.0f frames/s"
+                  % (done, cores, dt, frames_per_call / per_call),
+    }
+
+
+def measured_traffic(frames):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/run_profile.sh),
+    only if they were taken at this batch size; else None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.endswith("_hbm_traffic.json"):
+            try:
+                d = json.load(open(os.path.join(pdir, fn)))
+                if d.get("frames_per_launch") == frames and "xform_kernel<false>" in d.get("kernel", ""):
+                    best = d["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import importlib
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module("ac-3-acm-codec_amd")
+    eng = pkg.Engine(local_rank)                      # fails loudly without libac3mi.so / a GPU
+    desc = pkg.XformDesc(acmod=7, lfeon=1, output=7 | 16, bias=0.0)
+
+    S = args.frames
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    coef = torch.randn((S, 1, 6, N_CH, 256), device=dev, generator=g, dtype=torch.float32) * (2.0 ** -8)
+    delay = torch.zeros((S, N_CH, 128), device=dev, dtype=torch.float32)
+    out = torch.empty((S, 1, 6, N_CH, 256), device=dev, dtype=torch.float32)
+
+    def step():
+        eng.imdct_batch(desc, coef, delay, None, out=out, wait_torch=False)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = eng.timer_stop() / args.steps          # HIP events on the engine's own stream
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, kernel_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_frames = S * world * args.steps
+        value = total_frames / dt
+        achieved = BYTES_PER_FRAME * S / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "AC-3 5.1@48kHz frames/sec (batched decode transform: IMDCT-512 + window + overlap-add)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: batched decode, %d independent 5.1/48kHz frames per GPU, "
+                            "IMDCT-512 + KBD window + overlap-add, coefficients and PCM resident in HBM" % S,
+                "frames_per_gpu": S,
+                "channels": N_CH,
+                "blocks_per_frame": 6,
+                "parallelism": "streams sharded over %d GPU(s), no collective" % world,
+                "realtime_x_per_gpu": value / world * 0.032,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(S),
+                "kernel": "ac3mi::xform_kernel<false>",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

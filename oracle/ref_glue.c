@@ -43,3 +43,15 @@ long refglue_bitpos (a52_state_t * st, uint8_t * base)
 {
     return ((uint8_t *) st->buffer_start - base) * 8L - (long) st->bits_left;
 }
+
+/* C-side loop over the reference's own a52_imdct_512 so that bench.py's cpu_baseline
+ * ("kind": "reference") times liba52 itself and not ctypes call overhead.
+ * data: n planes of 256 floats (transformed in place), delay: n_chains planes of 256
+ * floats; plane k uses delay plane k % n_chains (a chain = one channel of one stream,
+ * walked block after block like a52_block does). */
+void refglue_imdct512_batch (sample_t * data, sample_t * delay, long n, long n_chains, sample_t bias)
+{
+    long k;
+    for (k = 0; k < n; k++)
+	a52_imdct_512 (data + 256 * k, delay + 256 * (k % n_chains), bias);
+}
