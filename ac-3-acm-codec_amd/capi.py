@@ -19,6 +19,15 @@ class XformDescC(ctypes.Structure):
     _fields_ = [("acmod", c_int), ("lfeon", c_int), ("output", c_int), ("bias", c_float)]
 
 
+class DecodeDescC(ctypes.Structure):
+    _fields_ = [("flags", c_int), ("level", c_float), ("bias", c_float), ("dynrng", c_int),
+                ("acmod", c_int), ("lfeon", c_int), ("frame_bytes", c_int)]
+
+
+class DecodeTapsC(ctypes.Structure):
+    _fields_ = [("d_coef", c_void_p), ("d_blksw", c_void_p), ("d_exp", c_void_p), ("d_bap", c_void_p)]
+
+
 _lib = None
 
 
@@ -72,5 +81,9 @@ def load_library():
     lib.ac3mi_xform_planes.argtypes = [ctypes.POINTER(XformDescC), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.ac3mi_imdct_batch.argtypes = [c_void_p, ctypes.POINTER(XformDescC), c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_int]
+    lib.ac3mi_syncinfo.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.ac3mi_decode_planes.argtypes = [ctypes.POINTER(DecodeDescC), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    lib.ac3mi_decode_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecodeTapsC)]
     _lib = lib
     return lib

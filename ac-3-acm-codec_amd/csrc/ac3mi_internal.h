@@ -7,11 +7,23 @@
 
 namespace ac3mi {
 
+// decoder front-end tables (device copy)
+struct DecTables {
+    int8_t la_neg[256];
+    uint16_t hth[3][50];
+    int8_t width[64];
+    uint8_t band_end[30];
+    float qlev[48];     // [0,3) 3-level  [3,8) 5-level  [8,16) 7-level  [16,27) 11-level  [27,43) 15-level
+};
+
 // Device-resident constant tables, built on the host in double precision.
 struct DeviceTables {
     float2 *tw_long;    // [8][16]  merged lane twiddles, long block
     float2 *tw_short;   // [8][16]  merged lane twiddles, short block
     float *window;      // [256]    KBD alpha=5 window (L52/imdct.c:364-372)
+    DecTables *dec;     // bit-allocation / dequantiser tables
+    uint16_t *lfsr_seq; // [65535] dither LFSR states in cycle order from state 1 (L52/parse.c:310-319)
+    uint16_t *lfsr_idx; // [65536] inverse: position of a state in the cycle
 };
 
 struct MixPlan {
@@ -36,6 +48,21 @@ int build_mix_plan(int acmod, int lfeon, int output, MixPlan *plan);
 
 hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream_t stream);
 
+struct DecodeLaunch {
+    const uint8_t *frames;
+    int frame_bytes, frame_stride, n_streams, frames_per_stream;
+    int req_flags, acmod, lfeon, dynrng_on;
+    float level;
+    float *coef;            // [S][F][6][n_in][256]
+    uint8_t *blksw;         // [S][F][6][nfchans]
+    uint32_t *status;       // [S][F]
+    uint16_t *lfsr;         // [S]
+    uint8_t *tap_exp;
+    int8_t *tap_bap;
+};
+hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
+void build_dec_tables(DecTables *t, uint16_t *lfsr_seq /*[65535]*/, uint16_t *lfsr_idx /*[65536]*/);
+
 void build_host_tables(float *window256, float2 *tw_long /*[8][16]*/, float2 *tw_short /*[8][16]*/);
 
 }  // namespace ac3mi
@@ -45,5 +72,9 @@ struct ac3mi_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     ac3mi::DeviceTables tab;
+    // decode workspace (coefficient planes + block-switch flags between the two kernels)
+    float *ws_coef;
+    uint8_t *ws_blksw;
+    size_t ws_coef_bytes, ws_blksw_bytes;
     std::string err;
 };

@@ -1,6 +1,8 @@
 // capi.hip — the C-ABI of libac3mi.so (include/ac3mi.h): context, device memory,
 // table construction and the batched entry points.
 #include "ac3mi_internal.h"
+#include "a52_levels.h"
+#include "spec_tables.h"
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -46,6 +48,45 @@ void build_host_tables(float *window, float2 *tw_long, float2 *tw_short)
             double b = -pi * (n - 0.25) / 128 - 2 * pi * n * k / 64 - pi * (k + 0.5) / 128;
             tw_short[l * 16 + k] = make_float2((float)cos(b), (float)sin(b));
         }
+}
+
+// decoder tables: L52/bit_allocate.c:31-101, L52/tables.h:49-246
+void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
+{
+    uint8_t la[256];
+    build_logadd(la);
+    for (int i = 0; i < 256; i++) t->la_neg[i] = (int8_t)-la[i];
+    memcpy(t->hth, kHth, sizeof t->hth);
+    memcpy(t->width, kWidth, sizeof t->width);
+    memcpy(t->band_end, kBandEnd, sizeof t->band_end);
+    // Q(x) = ROUND(32768 x) for the symmetric quantiser levels (L52/tables.h:49)
+    auto q = [](int num, int den) {
+        double x = 32768.0 * num / den;
+        return (float)(int)(x + (x > 0 ? 0.5 : -0.5));
+    };
+    memset(t->qlev, 0, sizeof t->qlev);
+    for (int i = 0; i < 3; i++) t->qlev[i] = q(2 * (i - 1), 3);
+    for (int i = 0; i < 5; i++) t->qlev[3 + i] = q(2 * (i - 2), 5);
+    for (int i = 0; i < 7; i++) t->qlev[8 + i] = q(2 * (i - 3), 7);
+    for (int i = 0; i < 11; i++) t->qlev[16 + i] = q(2 * (i - 5), 11);
+    for (int i = 0; i < 15; i++) t->qlev[27 + i] = q(2 * (i - 7), 15);
+    // dither generator (L52/parse.c:310-319, table L52/tables.h:213-246): one call advances a
+    // 16-bit Galois LFSR (feedback 0xa011) by 8 steps.  It is GF(2)-linear with period 65535,
+    // so the sequence from state 1 plus its inverse index give O(1) access to any later draw.
+    uint16_t step8[256];
+    step8[0] = 0;
+    for (int i = 1; i < 256; i <<= 1) {
+        uint16_t v = (i == 1) ? 0xa011 : (uint16_t)((step8[i >> 1] << 1) ^ ((step8[i >> 1] & 0x8000) ? 0xa011 : 0));
+        step8[i] = v;
+        for (int k = 1; k < i; k++) step8[i + k] = (uint16_t)(v ^ step8[k]);
+    }
+    memset(lfsr_idx, 0, 65536 * sizeof(uint16_t));
+    uint16_t s = 1;
+    for (int i = 0; i < 65535; i++) {
+        lfsr_seq[i] = s;
+        lfsr_idx[s] = (uint16_t)i;
+        s = (uint16_t)(step8[s >> 8] ^ (uint16_t)(s << 8));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -187,6 +228,17 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipMemcpy(ctx->tab.window, win.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->tab.tw_long, twl.data(), 128 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(ctx->tab.tw_short, tws.data(), 128 * sizeof(float2), hipMemcpyHostToDevice));
+    {
+        DecTables dt;
+        std::vector<uint16_t> seq(65535), idx(65536);
+        build_dec_tables(&dt, seq.data(), idx.data());
+        HIPCHK(ctx, hipMalloc(&ctx->tab.dec, sizeof dt));
+        HIPCHK(ctx, hipMalloc(&ctx->tab.lfsr_seq, 65535 * sizeof(uint16_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->tab.lfsr_idx, 65536 * sizeof(uint16_t)));
+        HIPCHK(ctx, hipMemcpy(ctx->tab.dec, &dt, sizeof dt, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_seq, seq.data(), 65535 * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_idx, idx.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     return AC3MI_OK;
 }
 
@@ -204,7 +256,10 @@ ac3mi_ctx *ac3mi_create(int device)
     ac3mi_ctx *ctx = new ac3mi_ctx();
     ctx->device = device;
     ctx->stream = nullptr;
-    ctx->tab = DeviceTables{nullptr, nullptr, nullptr};
+    ctx->tab = DeviceTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ctx->ws_coef = nullptr;
+    ctx->ws_blksw = nullptr;
+    ctx->ws_coef_bytes = ctx->ws_blksw_bytes = 0;
     if (ctx_init(ctx) != AC3MI_OK) {
         g_err = ctx->err;
         delete ctx;
@@ -221,6 +276,11 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->tab.window);
     (void)hipFree(ctx->tab.tw_long);
     (void)hipFree(ctx->tab.tw_short);
+    (void)hipFree(ctx->tab.dec);
+    (void)hipFree(ctx->tab.lfsr_seq);
+    (void)hipFree(ctx->tab.lfsr_idx);
+    (void)hipFree(ctx->ws_coef);
+    (void)hipFree(ctx->ws_blksw);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -333,6 +393,122 @@ int ac3mi_imdct_batch(ac3mi_ctx *ctx, const ac3mi_xform_desc *desc, const float 
     L.bias = desc->bias;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, launch_xform(ctx->tab, L, ctx->stream));
+    return AC3MI_OK;
+}
+
+int ac3mi_syncinfo(const uint8_t *buf, int *flags, int *sample_rate, int *bit_rate)
+{
+    static const int kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
+    static const uint8_t lfebit[8] = {0x10, 0x10, 0x04, 0x04, 0x04, 0x01, 0x04, 0x01};
+    if (!buf || buf[0] != 0x0b || buf[1] != 0x77) return 0;
+    if (buf[5] >= 0x60) return 0;
+    const int bsid = buf[5] >> 3, half = bsid < 9 ? 0 : bsid - 8;
+    const int acmod = buf[6] >> 5;
+    if (flags) *flags = (((buf[6] & 0xf8) == 0x50) ? AC3MI_DOLBY : acmod) | ((buf[6] & lfebit[acmod]) ? AC3MI_LFE : 0);
+    const int code = buf[4] & 63;
+    if (code >= 38) return 0;
+    const int rate = kbps[code >> 1];
+    if (bit_rate) *bit_rate = (rate * 1000) >> half;
+    switch (buf[4] & 0xc0) {
+    case 0x00: if (sample_rate) *sample_rate = 48000 >> half; return 4 * rate;
+    case 0x40: if (sample_rate) *sample_rate = 44100 >> half; return 2 * (320 * rate / 147 + (code & 1));
+    case 0x80: if (sample_rate) *sample_rate = 32000 >> half; return 6 * rate;
+    }
+    return 0;
+}
+
+int ac3mi_decode_planes(const ac3mi_decode_desc *desc, int *n_out, int *out_flags)
+{
+    if (!desc || desc->acmod < 0 || desc->acmod > 7) return AC3MI_ERR_ARG;
+    const int out = a52_granted_output(desc->flags & AC3MI_CHANNEL_MASK, desc->acmod);
+    if (out < 0) return AC3MI_ERR_ARG;
+    const int lfe = (desc->lfeon && (desc->flags & AC3MI_LFE)) ? AC3MI_LFE : 0;
+    if (n_out) *n_out = kNfchans[out] + (lfe ? 1 : 0);
+    if (out_flags) *out_flags = out | lfe;
+    return AC3MI_OK;
+}
+
+static int ensure_ws(ac3mi_ctx *ctx, size_t coef_bytes, size_t blksw_bytes)
+{
+    if (coef_bytes > ctx->ws_coef_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws_coef);
+        ctx->ws_coef = nullptr;
+        ctx->ws_coef_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_coef, coef_bytes));
+        ctx->ws_coef_bytes = coef_bytes;
+    }
+    if (blksw_bytes > ctx->ws_blksw_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws_blksw);
+        ctx->ws_blksw = nullptr;
+        ctx->ws_blksw_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_blksw, blksw_bytes));
+        ctx->ws_blksw_bytes = blksw_bytes;
+    }
+    return AC3MI_OK;
+}
+
+int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+                       int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
+                       uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status, const ac3mi_decode_taps *taps)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    if (!desc || !d_frames || !d_delay || !d_lfsr || !d_pcm || !d_status || n_streams < 0 ||
+        frames_per_stream < 0 || desc->frame_bytes < 8 || desc->frame_bytes > 3840 ||
+        frame_stride < ((desc->frame_bytes + 3) & ~3) || (frame_stride & 3) || ((uintptr_t)d_frames & 3)) {
+        ctx->err = "ac3mi_decode_batch: bad argument";
+        return AC3MI_ERR_ARG;
+    }
+    int n_out = 0, out_flags = 0;
+    if (ac3mi_decode_planes(desc, &n_out, &out_flags) != AC3MI_OK) {
+        ctx->err = "ac3mi_decode_batch: requested output not supported (a52_frame would return 1)";
+        return AC3MI_ERR_ARG;
+    }
+    XformLaunch X;
+    if (build_mix_plan(desc->acmod, desc->lfeon, out_flags, &X.plan) != AC3MI_OK) {
+        ctx->err = "ac3mi_decode_batch: no mix plan for this acmod/output";
+        return AC3MI_ERR_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nfr = (size_t)n_streams * frames_per_stream;
+    float *coef = taps && taps->d_coef ? taps->d_coef : nullptr;
+    uint8_t *blksw = taps && taps->d_blksw ? taps->d_blksw : nullptr;
+    {
+        int r = ensure_ws(ctx, coef ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float),
+                          blksw ? 0 : nfr * 6 * X.plan.nfchans + 4);
+        if (r != AC3MI_OK) return r;
+    }
+    if (!coef) coef = ctx->ws_coef;
+    if (!blksw) blksw = ctx->ws_blksw;
+
+    DecodeLaunch D;
+    D.frames = d_frames;
+    D.frame_bytes = desc->frame_bytes;
+    D.frame_stride = frame_stride;
+    D.n_streams = n_streams;
+    D.frames_per_stream = frames_per_stream;
+    D.req_flags = desc->flags;
+    D.acmod = desc->acmod;
+    D.lfeon = desc->lfeon ? 1 : 0;
+    D.dynrng_on = desc->dynrng ? 1 : 0;
+    D.level = desc->level;
+    D.coef = coef;
+    D.blksw = blksw;
+    D.status = d_status;
+    D.lfsr = d_lfsr;
+    D.tap_exp = taps ? taps->d_exp : nullptr;
+    D.tap_bap = taps ? taps->d_bap : nullptr;
+    HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
+
+    X.coef = coef;
+    X.blksw = blksw;
+    X.delay = d_delay;
+    X.pcm = d_pcm;
+    X.n_streams = n_streams;
+    X.frames = frames_per_stream;
+    X.bias = desc->bias;
+    HIPCHK(ctx, launch_xform(ctx->tab, X, ctx->stream));
     return AC3MI_OK;
 }
 

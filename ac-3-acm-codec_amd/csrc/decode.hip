@@ -1,0 +1,919 @@
+// decode.hip — AC-3 frame front end on gfx950: BSI + audio-block side information,
+// exponent decode, parametric bit allocation, mantissa unpack + dequantisation, dither,
+// coupling, rematrixing.  Output: the dequantised, gain-scaled coefficient planes that
+// xform.hip turns into PCM.  Replaces a52_frame (L52/parse.c:131-205) and everything in
+// a52_block up to the transform stage (L52/parse.c:558-879), a52_bit_allocate
+// (L52/bit_allocate.c:124-265) and the bit reader (L52/bitstream.c/.h).
+//
+// One wavefront (= one 64-thread workgroup) owns one stream and walks its frames in
+// order, because the dither LFSR and the exponent / bit-allocation state carry over.
+//  * the frame is staged once into LDS as byte-swapped dwords; every bit field is then a
+//    2-dword LDS read + funnel shift
+//  * side information is serial: it is parsed redundantly by all lanes on wave-uniform
+//    values (scalar-unit work)
+//  * exponents: one lane per 7-bit group, wavefront prefix sum of the deltas
+//  * bit allocation: one lane per channel runs the band recurrences
+//  * mantissas: every lane takes a contiguous run of the block's coefficient stream;
+//    two wavefront scans give the bit offset and the grouped-code rank of every
+//    coefficient, a third gives the dither draw index (the LFSR is GF(2)-linear, so the
+//    k-th draw is a table lookup: lfsr_seq[(lfsr_idx[state] + k) mod 65535])
+//
+// Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
+#include "ac3mi_internal.h"
+#include "a52_levels.h"
+
+namespace ac3mi {
+
+constexpr int MAX_FRAME_BYTES = 3840;
+constexpr int FR_WORDS = MAX_FRAME_BYTES / 4 + 4;
+constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dwords, conflict-free across rows
+
+__device__ const uint8_t k_nfchans[11] = {2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2};
+__device__ const float k_clev[4] = {(float)AC3MI_G_3DB, (float)AC3MI_G_45DB, (float)AC3MI_G_6DB, (float)AC3MI_G_45DB};
+__device__ const float k_slev[4] = {(float)AC3MI_G_3DB, (float)AC3MI_G_6DB, 0.f, (float)AC3MI_G_6DB};
+__device__ const uint8_t k_cpl_bnd0[16] = {31, 35, 37, 39, 41, 42, 43, 44, 45, 45, 46, 46, 47, 47, 48, 48};
+__device__ const int k_remat_edge[5] = {13, 25, 37, 61, 253};
+__device__ const int k_slowgain[4] = {0x540, 0x4d8, 0x478, 0x410};
+__device__ const int k_dbpb[4] = {0xc00, 0x500, 0x300, 0x100};
+__device__ const int k_floors[8] = {0x910, 0x950, 0x990, 0x9d0, 0xa10, 0xa90, 0xb10, 0x1400};
+__device__ const uint16_t k_kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
+
+// channel slots: 0..4 = fbw, 5 = lfe, 6 = coupling channel
+struct DecLDS {
+    uint32_t fr[FR_WORDS];
+    uint8_t exp[7][ROW];
+    int8_t bap[7][ROW];
+    int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
+    float cplco[5][18];
+    float plane[6][256];                  // 0..4 fbw, 5 = lfe
+    uint16_t goff[3][512];                // bit offset of the first member of each 3/5/11-level group
+    uint8_t cplbnd[20];                   // coupling sub-band -> band
+    int16_t seg_base[9];                  // mantissa stream segments
+    uint8_t seg_ch[8], seg_start[8];
+    float qlev[48];                       // 3-, 5-, 7-, 11-, 15-level dequantiser values
+    int8_t la_neg[256];
+    uint16_t hth[50];
+    int8_t width[64];
+    uint8_t band_end[30];
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// n in 1..32: the n bits starting at bit `pos`
+__device__ __forceinline__ uint32_t peek(const uint32_t *fr, uint32_t pos, int n)
+{
+    uint32_t w = pos >> 5;
+    w = w < (uint32_t)(FR_WORDS - 2) ? w : (uint32_t)(FR_WORDS - 2);
+    const uint64_t v = ((uint64_t)fr[w] << 32) | fr[w + 1];
+    return (uint32_t)((v << (pos & 31)) >> (64 - n));
+}
+__device__ __forceinline__ int32_t speek(const uint32_t *fr, uint32_t pos, int n)
+{
+    return ((int32_t)(peek(fr, pos, n) << (32 - n))) >> (32 - n);
+}
+
+struct Rd {                                   // wave-uniform serial reader
+    const uint32_t *fr;
+    uint32_t pos;
+    __device__ __forceinline__ uint32_t get(int n)
+    {
+        if (n == 0) return 0;
+        uint32_t v = rfl(peek(fr, pos, n));
+        pos += n;
+        return v;
+    }
+    __device__ __forceinline__ int32_t sget(int n)
+    {
+        int32_t v = (int32_t)rfl((uint32_t)speek(fr, pos, n));
+        pos += n;
+        return v;
+    }
+};
+
+__device__ __forceinline__ float sf_of(int e) { return __int_as_float((127 - 15 - e) << 23); }   // 2^-(15+e)
+
+// wavefront inclusive prefix sum
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// stream-persistent decoder fields (wave-uniform)
+struct St {
+    int fscod, halfrate, acmod, lfeon, nf;
+    float clev, slev, level, bias_unused, dynrng;
+    int output, dynrnge;
+    int chincpl, phsflginu, cplstrtmant, cplendmant, ncplbnd, cplstrtbnd;
+    uint32_t cplbndstrc;
+    int rematflg;
+    int endmant[5];
+    int bai, csnroffst;
+    int cbai[7];            // per-slot fsnroffst<<3 | fgaincod
+    int deltbae[6];         // 0..4 fbw, 5 = cpl
+    int cplfleak, cplsleak;
+    uint32_t lfsr;
+};
+
+struct DecodeParams {
+    const uint8_t *frames;
+    float *coef;
+    uint8_t *blksw;
+    uint32_t *status;
+    uint16_t *lfsr_state;
+    uint8_t *tap_exp;       // optional [S][F][6][7][256]
+    int8_t *tap_bap;        // optional, same shape
+    const uint16_t *lfsr_seq;   // [65535] LFSR states in cycle order starting at 1
+    const uint16_t *lfsr_idx;   // [65536] position of a state in that cycle
+    const DecTables *tab;
+    int n_streams, frames_per_stream, frame_stride, frame_bytes;
+    int req_flags;
+    float level;
+    int dynrng_on;
+    int acmod, lfeon;       // expected coded configuration (frame 0 of the batch)
+    int n_in, nfchans;
+};
+
+// ---------------------------------------------------------------------------
+// exponents: L52/parse.c:218-270.  ngrps groups of 7 bits at `pos`; returns 1 on a
+// reserved code or an exponent outside 0..24.
+__device__ int read_exponents(const uint32_t *fr, uint32_t pos, int strategy, int ngrps, int absexp,
+                              uint8_t *dst, int lane)
+{
+    const int rep = 1 << (strategy - 1);
+    int carry = absexp, bad = 0;
+    for (int g0 = 0; g0 < ngrps; g0 += 64) {
+        const int g = g0 + lane;
+        int d0 = 0, d1 = 0, d2 = 0, ok = 1;
+        if (g < ngrps) {
+            const int code = (int)peek(fr, pos + 7 * g, 7);
+            ok = code < 125;
+            d0 = code / 25 - 2;
+            d1 = (code / 5) % 5 - 2;
+            d2 = code % 5 - 2;
+            if (!ok) d0 = d1 = d2 = 0;
+        }
+        const int incl = wave_incl_scan(d0 + d1 + d2, lane);
+        const int e0 = carry + incl - (d1 + d2), e1 = e0 + d1, e2 = e1 + d2;
+        if (g < ngrps) {
+            if (!ok || e0 < 0 || e0 > 24 || e1 < 0 || e1 > 24 || e2 < 0 || e2 > 24) bad = 1;
+            uint8_t *p = dst + 3 * g * rep;
+            for (int r = 0; r < rep; r++) {
+                p[r] = (uint8_t)e0;
+                p[rep + r] = (uint8_t)e1;
+                p[2 * rep + r] = (uint8_t)e2;
+            }
+        }
+        carry += __shfl(incl, 63, 64);
+    }
+    return __any(bad) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// bit allocation, one lane = one channel: L52/bit_allocate.c:124-265
+
+struct BaCtx {
+    int fdecay, fgain, sdecay, sgain, dbknee, floor, snroffset, halfrate, fast, slow;
+    const uint16_t *hth;
+    const int8_t *deltba;       // may be null
+};
+
+__device__ __forceinline__ void ba_leak(BaCtx &c, int psd)
+{
+    c.fast += c.fdecay;
+    if (c.fast > psd + c.fgain) c.fast = psd + c.fgain;
+    c.slow += c.sdecay;
+    if (c.slow > psd + c.sgain) c.slow = psd + c.sgain;
+}
+
+__device__ __forceinline__ int ba_mask(const BaCtx &c, int mask, int psd, int band)
+{
+    const int h = c.hth[band >> c.halfrate];
+    if (psd > c.dbknee) mask -= (psd - c.dbknee) >> 2;
+    if (mask > h) mask = h;
+    mask -= c.snroffset + 128 * (c.deltba ? c.deltba[band] : 0);
+    mask = (mask > 0) ? 0 : ((-mask) >> 5);
+    return mask - c.floor;
+}
+
+__device__ __forceinline__ int8_t ba_width(const int8_t *width, int a)
+{
+    return a <= -64 ? 16 : a >= 0 ? 0 : width[a + 63];
+}
+
+__device__ void bit_allocate_lane(const DecLDS &L, BaCtx c, int bndstart, int start, int end, const uint8_t *e,
+                                  int8_t *bap)
+{
+    int band = bndstart, bin = start, psd = 0, mask;
+    if (start == 0) {
+        int lowcomp = 0;
+        const int last = end - 1;
+        do {
+            if (band < last) {
+                if (e[band + 1] == e[band] - 2) lowcomp = 384;
+                else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
+            }
+            psd = 128 * e[band];
+            mask = ba_mask(c, psd + c.fgain + lowcomp, psd, band);
+            bap[band] = ba_width(L.width, mask + 4 * e[band]);
+            band++;
+        } while (band < 3 || (band < 7 && e[band] > e[band - 1]));
+        c.fast = psd + c.fgain;
+        c.slow = psd + c.sgain;
+        while (band < 7) {
+            if (band < last) {
+                if (e[band + 1] == e[band] - 2) lowcomp = 384;
+                else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
+            }
+            psd = 128 * e[band];
+            ba_leak(c, psd);
+            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
+            mask = ba_mask(c, mask, psd, band);
+            bap[band] = ba_width(L.width, mask + 4 * e[band]);
+            band++;
+        }
+        if (end == 7) return;
+        do {
+            if (e[band + 1] == e[band] - 2) lowcomp = 320;
+            else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
+            psd = 128 * e[band];
+            ba_leak(c, psd);
+            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
+            mask = ba_mask(c, mask, psd, band);
+            bap[band] = ba_width(L.width, mask + 4 * e[band]);
+            band++;
+        } while (band < 20);
+        while (lowcomp > 128) {
+            lowcomp -= 128;
+            psd = 128 * e[band];
+            ba_leak(c, psd);
+            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
+            mask = ba_mask(c, mask, psd, band);
+            bap[band] = ba_width(L.width, mask + 4 * e[band]);
+            band++;
+        }
+        bin = band;
+    }
+    do {
+        const int first = bin;
+        const int stop = L.band_end[band - 20] < end ? L.band_end[band - 20] : end;
+        psd = 128 * e[bin++];
+        while (bin < stop) {
+            const int next = 128 * e[bin++], d = next - psd;
+            const int q = d >> 9;
+            if (q <= -2) psd = next;
+            else if (q == -1) { int a = (-d) >> 1; psd = next + L.la_neg[a > 255 ? 255 : a]; }
+            else if (q == 0) psd += L.la_neg[d >> 1];
+        }
+        ba_leak(c, psd);
+        mask = ba_mask(c, c.fast < c.slow ? c.fast : c.slow, psd, band);
+        band++;
+        for (bin = first; bin < stop; bin++) bap[bin] = ba_width(L.width, mask + 4 * e[bin]);
+    } while (bin < end);
+}
+
+// ---------------------------------------------------------------------------
+// mantissa helpers
+
+__device__ __forceinline__ int item_bits_plain(int w) { return w > 0 ? w : 0; }   // widths 3,4,5..16; grouped/zero: 0
+
+// dequantised value of a non-grouped, non-zero mantissa of width w at bit offset off
+__device__ __forceinline__ float plain_value(const DecLDS &L, int w, uint32_t off)
+{
+    if (w == 3) return L.qlev[8 + peek(L.fr, off, 3)];
+    if (w == 4) return L.qlev[27 + peek(L.fr, off, 4)];
+    return (float)(speek(L.fr, off, w) * (1 << (16 - w)));
+}
+
+// member m (0 = first) of the grouped code `code` of kind k (0: 3-level/5 bits, 1: 5-level/7 bits, 2: 11-level/7 bits)
+__device__ __forceinline__ float group_value(const DecLDS &L, int kind, int code, int m)
+{
+    if (kind == 0) {
+        if (code >= 27) return 0.f;
+        const int idx = m == 0 ? code / 9 : m == 1 ? (code / 3) % 3 : code % 3;
+        return L.qlev[idx];
+    }
+    if (kind == 1) {
+        if (code >= 125) return 0.f;
+        const int idx = m == 0 ? code / 25 : m == 1 ? (code / 5) % 5 : code % 5;
+        return L.qlev[3 + idx];
+    }
+    if (code >= 121) return 0.f;
+    return L.qlev[16 + (m == 0 ? code / 11 : code % 11)];
+}
+
+__device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t idx0, int k)
+{
+    // k-th draw (k = 0 first) = state after k+1 steps
+    uint32_t i = idx0 + (uint32_t)k + 1;
+    i %= 65535u;
+    const int16_t ns = (int16_t)P.lfsr_seq[i];
+    return (int16_t)((3 * ns) >> 2);
+}
+
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
+{
+    __shared__ DecLDS L;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    if (s >= P.n_streams) return;
+
+    // ---- constant tables into LDS ----
+    for (int i = lane; i < 256; i += 64) L.la_neg[i] = P.tab->la_neg[i];
+    if (lane < 50) L.hth[lane] = 0;
+    L.width[lane] = P.tab->width[lane];
+    if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
+    if (lane < 48) L.qlev[lane] = P.tab->qlev[lane];
+    for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
+    for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
+    for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
+
+    St st;
+    st.fscod = st.halfrate = st.acmod = st.lfeon = 0;
+    st.nf = 0;
+    st.clev = st.slev = st.level = st.dynrng = 0.f;
+    st.output = 0;
+    st.dynrnge = 1;
+    st.chincpl = st.phsflginu = st.cplstrtmant = st.cplendmant = st.ncplbnd = st.cplstrtbnd = 0;
+    st.cplbndstrc = 0;
+    st.rematflg = 0;
+    for (int i = 0; i < 5; i++) st.endmant[i] = 0;
+    st.bai = st.csnroffst = 0;
+    for (int i = 0; i < 7; i++) st.cbai[i] = 0;
+    for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
+    st.cplfleak = st.cplsleak = 0;
+    st.lfsr = P.lfsr_state[s];
+    int hth_fscod = -1;
+
+    for (int f = 0; f < P.frames_per_stream; f++) {
+        const size_t fidx = (size_t)s * P.frames_per_stream + f;
+        const uint8_t *src = P.frames + fidx * P.frame_stride;
+        float *cout = P.coef + fidx * 6 * P.n_in * 256;
+        uint32_t status = 0;
+
+        // ---- stage the frame: byte-swapped dwords, zero padded ----
+        {
+            const int nw = (P.frame_bytes + 3) >> 2;
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+            for (int i = lane; i < FR_WORDS; i += 64) {
+                uint32_t v = 0;
+                if (i < nw) {
+                    v = s32[i];
+                    const int rem = P.frame_bytes - 4 * i;
+                    if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+                    v = __builtin_bswap32(v);
+                }
+                L.fr[i] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        Rd rd{L.fr, 0};
+        // ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205) ----
+        bool hdr_ok = true;
+        {
+            const uint32_t w0 = rfl(L.fr[0]), w1 = rfl(L.fr[1]);
+            const int b4 = (w1 >> 24) & 0xff, b5 = (w1 >> 16) & 0xff, b6 = (w1 >> 8) & 0xff;
+            if ((w0 >> 16) != 0x0b77) hdr_ok = false;
+            if (b5 >= 0x60) hdr_ok = false;
+            if ((b4 & 63) >= 38 || (b4 & 0xc0) == 0xc0) hdr_ok = false;
+            if (hdr_ok) {
+                st.fscod = b4 >> 6;
+                const int bsid = b5 >> 3;
+                st.halfrate = bsid < 9 ? 0 : bsid - 8;
+                st.acmod = b6 >> 5;
+                if (st.acmod != P.acmod) hdr_ok = false;
+                const int code = b4 & 63, rate = k_kbps[code >> 1];
+                const int fbytes = st.fscod == 0 ? 4 * rate : st.fscod == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
+                if (fbytes != P.frame_bytes) hdr_ok = false;
+            }
+        }
+        if (hdr_ok) {
+            int acmod = st.acmod;
+            rd.pos = 6 * 8 + 3;
+            if (acmod == 2 && rd.get(2) == 2) acmod = 10;                 // dsurmod -> DOLBY
+            st.clev = st.slev = 0.f;
+            if ((acmod & 1) && acmod != 1) st.clev = k_clev[rd.get(2)];
+            if (acmod & 4) st.slev = k_slev[rd.get(2)];
+            st.lfeon = rd.get(1);
+            if (st.lfeon != P.lfeon) hdr_ok = false;
+            float level = P.level;
+            st.output = a52_downmix_init_hd(acmod, P.req_flags, &level, st.clev, st.slev);
+            if (st.output < 0) hdr_ok = false;
+            if (hdr_ok) {
+                if (st.lfeon && (P.req_flags & AC3MI_LFE)) st.output |= AC3MI_LFE;
+                st.dynrng = st.level = level * 2;
+                st.dynrnge = P.dynrng_on;
+                for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
+                int twice = !acmod;
+                do {
+                    rd.get(5);
+                    if (rd.get(1)) rd.get(8);
+                    if (rd.get(1)) rd.get(8);
+                    if (rd.get(1)) rd.get(7);
+                } while (twice--);
+                rd.get(2);
+                if (rd.get(1)) rd.get(14);
+                if (rd.get(1)) rd.get(14);
+                if (rd.get(1)) {
+                    int len = rd.get(6);
+                    do rd.get(8); while (len--);
+                }
+                st.nf = k_nfchans[st.acmod];
+                if (hth_fscod != st.fscod) {
+                    if (lane < 50) L.hth[lane] = P.tab->hth[st.fscod][lane];
+                    hth_fscod = st.fscod;
+                }
+                status |= (uint32_t)st.output << 16;
+            }
+        }
+        if (!hdr_ok) status |= 0x100u | 0x3fu;
+
+        bool frame_dead = !hdr_ok;
+        for (int blk = 0; blk < 6; blk++) {
+            float *cblk = cout + (size_t)blk * P.n_in * 256;
+            int err = frame_dead ? 1 : 0;
+            int blkswm = 0, dithmask = 0;
+            float gain[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            const int nf = st.nf;
+
+            if (!err) do {
+                // ---- side information: parse.c:572-701 ----
+                for (int i = 0; i < nf; i++) blkswm |= rd.get(1) << i;
+                for (int i = 0; i < nf; i++) dithmask |= rd.get(1) << i;
+                int twice = !st.acmod;
+                do {
+                    if (rd.get(1)) {
+                        const int code = rd.sget(8);
+                        if (st.dynrnge) {
+                            const float range = (float)(((code & 0x1f) | 0x20) << 13) * sf_of(3 - (code >> 5));
+                            st.dynrng = st.level * range;
+                        }
+                    }
+                } while (twice--);
+
+                if (rd.get(1)) {                                            // cplstre
+                    st.chincpl = 0;
+                    if (rd.get(1)) {                                        // cplinu
+                        for (int i = 0; i < nf; i++) st.chincpl |= rd.get(1) << i;
+                        if (st.acmod < 2) { err = 1; break; }
+                        if (st.acmod == 2) st.phsflginu = rd.get(1);
+                        const int begf = rd.get(4), endf = rd.get(4);
+                        if (endf + 3 - begf < 0) { err = 1; break; }
+                        const int nsub = endf + 3 - begf;
+                        st.ncplbnd = nsub;
+                        st.cplstrtbnd = k_cpl_bnd0[begf];
+                        st.cplstrtmant = begf * 12 + 37;
+                        st.cplendmant = endf * 12 + 73;
+                        st.cplbndstrc = 0;
+                        for (int i = 0; i < nsub - 1; i++)
+                            if (rd.get(1)) { st.cplbndstrc |= 1u << i; st.ncplbnd--; }
+                    }
+                }
+                if (st.chincpl) {                                           // coupling coordinates
+                    int any = 0;
+                    for (int i = 0; i < nf; i++)
+                        if ((st.chincpl >> i) & 1)
+                            if (rd.get(1)) {
+                                const int master = 3 * rd.get(2);
+                                any = 1;
+                                for (int j = 0; j < st.ncplbnd; j++) {
+                                    const int ex = rd.get(4);
+                                    int ma = rd.get(4);
+                                    ma = (ex == 15) ? (ma << 14) : ((ma | 0x10) << 13);
+                                    const float co = (float)ma * sf_of(ex + master);
+                                    if (lane == 0) L.cplco[i][j] = co;
+                                }
+                            }
+                    if (st.acmod == 2 && st.phsflginu && any)
+                        for (int j = 0; j < st.ncplbnd; j++)
+                            if (rd.get(1) && lane == 0) L.cplco[1][j] = -L.cplco[1][j];
+                }
+                if (st.acmod == 2 && rd.get(1)) {                           // rematstr
+                    const int end = st.chincpl ? st.cplstrtmant : 253;
+                    int i = 0;
+                    st.rematflg = 0;
+                    do st.rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                }
+                int cplexpstr = 0, lfeexpstr = 0, chexp = 0;   // chexp: 2 bits per channel
+                if (st.chincpl) cplexpstr = rd.get(2);
+                for (int i = 0; i < nf; i++) chexp |= rd.get(2) << (2 * i);
+                if (st.lfeon) lfeexpstr = rd.get(1);
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    if (i < nf && !err && ((chexp >> (2 * i)) & 3)) {
+                        if ((st.chincpl >> i) & 1) st.endmant[i] = st.cplstrtmant;
+                        else {
+                            const int bw = rd.get(6);
+                            if (bw > 60) err = 1;
+                            else st.endmant[i] = bw * 3 + 73;
+                        }
+                    }
+                if (err) break;
+
+                // ---- exponents: parse.c:703-736 ----
+                int redo = 0;
+                if (cplexpstr) {
+                    const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
+                    const int e0 = rd.get(4) << 1;
+                    redo = 64;
+                    if (read_exponents(L.fr, rd.pos, cplexpstr, ngrp, e0, &L.exp[6][st.cplstrtmant], lane)) { err = 1; break; }
+                    rd.pos += 7 * ngrp;
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int es = (chexp >> (2 * i)) & 3;
+                    if (i < nf && !err && es) {
+                        const int gs = 3 << (es - 1), ngrp = (st.endmant[i] + gs - 4) / gs;
+                        redo |= 1 << i;
+                        const int e0 = rd.get(4);
+                        if (lane == 0) L.exp[i][0] = (uint8_t)e0;
+                        if (read_exponents(L.fr, rd.pos, es, ngrp, e0, &L.exp[i][1], lane)) err = 1;
+                        rd.pos += 7 * ngrp;
+                        rd.get(2);                                          // gainrng
+                    }
+                }
+                if (err) break;
+                if (lfeexpstr) {
+                    redo |= 32;
+                    const int e0 = rd.get(4);
+                    if (lane == 0) L.exp[5][0] = (uint8_t)e0;
+                    if (read_exponents(L.fr, rd.pos, lfeexpstr, 2, e0, &L.exp[5][1], lane)) { err = 1; break; }
+                    rd.pos += 14;
+                }
+
+                // ---- bit-allocation parameters: parse.c:738-772 ----
+                if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
+                if (rd.get(1)) {
+                    redo = 127;
+                    st.csnroffst = rd.get(6);
+                    if (st.chincpl) st.cbai[6] = rd.get(7);
+#pragma unroll
+                    for (int i = 0; i < 5; i++) if (i < nf) st.cbai[i] = rd.get(7);
+                    if (st.lfeon) st.cbai[5] = rd.get(7);
+                }
+                if (st.chincpl && rd.get(1)) {
+                    redo |= 64;
+                    st.cplfleak = 9 - rd.get(3);
+                    st.cplsleak = 9 - rd.get(3);
+                }
+                if (rd.get(1)) {                                            // deltbaie
+                    redo = 127;
+                    if (st.chincpl) st.deltbae[5] = rd.get(2);
+#pragma unroll
+                    for (int i = 0; i < 5; i++) if (i < nf) st.deltbae[i] = rd.get(2);
+#pragma unroll
+                    for (int pass = 0; pass < 6; pass++) {
+                        const int slot = pass == 0 ? 5 : pass - 1;          // cpl first, then fbw (parse.c:763-771)
+                        if (err || pass > nf) continue;
+                        if (slot == 5 && !st.chincpl) continue;
+                        if (st.deltbae[slot] != 1) continue;
+                        // parse_deltba: parse.c:272-294
+                        if (lane < 50) L.deltba[slot][lane] = 0;
+                        int nseg = rd.get(3), band = 0;
+                        do {
+                            band += rd.get(5);
+                            int len = rd.get(4), d = rd.get(3);
+                            d -= (d >= 4) ? 3 : 4;
+                            if (!len) continue;
+                            if (band + len >= 50) { err = 1; break; }
+                            if (lane < len) L.deltba[slot][band + lane] = (int8_t)d;
+                            band += len;
+                        } while (nseg--);
+                    }
+                    if (err) break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // ---- bit allocation: parse.c:774-798 ----
+                if (redo) {
+                    bool allzero = !st.csnroffst && !(st.chincpl && (st.cbai[6] >> 3)) && !(st.lfeon && (st.cbai[5] >> 3));
+#pragma unroll
+                    for (int i = 0; i < 5; i++)
+                        if (i < nf && (st.cbai[i] >> 3)) allzero = false;
+                    if (allzero) {
+                        for (int i = lane; i < 7 * ROW; i += 64) (&L.bap[0][0])[i] = 0;
+                    } else {
+                        // lane -> channel slot
+                        bool act = false;
+                        int start = 0, end = 0, bndstart = 0, mybai = 0, mydeltbae = 2, fl0 = 0, sl0 = 0;
+                        if (lane < 5) {
+                            act = lane < nf && (redo & (1 << lane));
+                            end = lane == 0 ? st.endmant[0] : lane == 1 ? st.endmant[1] : lane == 2 ? st.endmant[2]
+                                : lane == 3 ? st.endmant[3] : st.endmant[4];
+                            mybai = lane == 0 ? st.cbai[0] : lane == 1 ? st.cbai[1] : lane == 2 ? st.cbai[2]
+                                  : lane == 3 ? st.cbai[3] : st.cbai[4];
+                            mydeltbae = lane == 0 ? st.deltbae[0] : lane == 1 ? st.deltbae[1] : lane == 2 ? st.deltbae[2]
+                                      : lane == 3 ? st.deltbae[3] : st.deltbae[4];
+                        } else if (lane == 5) {
+                            act = st.lfeon && (redo & 32);
+                            end = 7;
+                            mybai = st.cbai[5];
+                            mydeltbae = 2;
+                        } else if (lane == 6) {
+                            act = st.chincpl && (redo & 64);
+                            start = st.cplstrtmant;
+                            end = st.cplendmant;
+                            bndstart = st.cplstrtbnd;
+                            mybai = st.cbai[6];
+                            mydeltbae = st.deltbae[5];
+                            fl0 = st.cplfleak << 8;
+                            sl0 = st.cplsleak << 8;
+                        }
+                        if (act && end > start) {
+                            BaCtx c;
+                            c.halfrate = st.halfrate;
+                            c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
+                            c.fgain = 128 + 128 * (mybai & 7);
+                            c.sdecay = (15 + 2 * (st.bai >> 9)) >> c.halfrate;
+                            c.sgain = k_slowgain[(st.bai >> 5) & 3];
+                            c.dbknee = k_dbpb[(st.bai >> 3) & 3];
+                            c.hth = L.hth;
+                            c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[lane == 6 ? 5 : lane];
+                            const int fl = k_floors[st.bai & 7];
+                            c.snroffset = 960 - 64 * st.csnroffst - 4 * (mybai >> 3) + fl;
+                            c.floor = fl >> 5;
+                            c.fast = fl0;
+                            c.slow = sl0;
+                            bit_allocate_lane(L, c, bndstart, start, end, L.exp[lane], L.bap[lane]);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                if (rd.get(1)) {                                            // skip field
+                    const int n = rd.get(9);
+                    rd.pos += 8 * n;
+                }
+            } while (0);
+
+            // optional stage taps
+            if (P.tap_exp) {
+                uint8_t *te = P.tap_exp + (fidx * 6 + blk) * 7 * 256;
+                int8_t *tb = P.tap_bap + (fidx * 6 + blk) * 7 * 256;
+                for (int c = 0; c < 7; c++)
+                    for (int i = lane; i < 256; i += 64) { te[c * 256 + i] = L.exp[c][i]; tb[c * 256 + i] = L.bap[c][i]; }
+            }
+
+            if (!err) {
+                // ---- gains: parse.c:810-811 ----
+                a52_downmix_coeff_hd(gain, st.acmod, st.output, st.dynrng, st.clev, st.slev);
+
+                // ---- mantissa stream segments (parse.c:813-879 order) ----
+                int nseg = 0, total = 0, cpl_done = 0;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    if (i >= nf) continue;
+                    if (lane == 0) { L.seg_ch[nseg] = (uint8_t)i; L.seg_start[nseg] = 0; L.seg_base[nseg] = (int16_t)total; }
+                    nseg++; total += st.endmant[i];
+                    if (((st.chincpl >> i) & 1) && !cpl_done) {
+                        cpl_done = 1;
+                        if (lane == 0) { L.seg_ch[nseg] = 6; L.seg_start[nseg] = (uint8_t)st.cplstrtmant; L.seg_base[nseg] = (int16_t)total; }
+                        nseg++; total += st.cplendmant - st.cplstrtmant;
+                    }
+                }
+                if (st.lfeon) {
+                    if (lane == 0) { L.seg_ch[nseg] = 5; L.seg_start[nseg] = 0; L.seg_base[nseg] = (int16_t)total; }
+                    nseg++; total += 7;
+                }
+                if (lane == 0) L.seg_base[nseg] = (int16_t)total;
+                if (st.chincpl && lane == 0) {                              // sub-band -> band (parse.c:448-456)
+                    uint32_t strc = st.cplbndstrc;
+                    int bnd = 0, nsub = (st.cplendmant - st.cplstrtmant) / 12;
+                    for (int sb = 0; sb < nsub; sb++) {
+                        L.cplbnd[sb] = (uint8_t)bnd;
+                        if (!(strc & 1)) bnd++;
+                        strc >>= 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                const int R = (total + 63) >> 6;
+                const int t0 = lane * R < total ? lane * R : total;
+                const int t1 = (lane + 1) * R < total ? (lane + 1) * R : total;
+                const int ncpl_dith = __popc(st.chincpl & dithmask);
+
+                // pass 1: grouped-code ranks and dither draws
+                int n3 = 0, n5 = 0, n11 = 0, nd = 0;
+                {
+                    int k = 0;
+                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
+                    for (int t = t0; t < t1; t++) {
+                        while (t >= L.seg_base[k + 1]) k++;
+                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
+                        const int w = L.bap[ch][bin];
+                        n3 += w == -1; n5 += w == -2; n11 += w == -3;
+                        if (w == 0) nd += ch == 6 ? ncpl_dith : (ch < 5 ? ((dithmask >> ch) & 1) : 0);
+                    }
+                }
+                const int r3 = wave_incl_scan(n3, lane) - n3, r5 = wave_incl_scan(n5, lane) - n5;
+                const int r11 = wave_incl_scan(n11, lane) - n11;
+                const int rdi = wave_incl_scan(nd, lane);
+                const int rd0 = rdi - nd, nd_total = __shfl(rdi, 63, 64);
+
+                // pass 2: bits per lane
+                int nbits = 0;
+                {
+                    int k = 0, c3 = r3, c5 = r5, c11 = r11;
+                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
+                    for (int t = t0; t < t1; t++) {
+                        while (t >= L.seg_base[k + 1]) k++;
+                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
+                        const int w = L.bap[ch][bin];
+                        if (w > 0) nbits += w;
+                        else if (w == -1) { if (c3 % 3 == 0) nbits += 5; c3++; }
+                        else if (w == -2) { if (c5 % 3 == 0) nbits += 7; c5++; }
+                        else if (w == -3) { if ((c11 & 1) == 0) nbits += 7; c11++; }
+                    }
+                }
+                const int bi = wave_incl_scan(nbits, lane);
+                const uint32_t mant_pos = rd.pos;
+                uint32_t off = mant_pos + (uint32_t)(bi - nbits);
+                rd.pos = mant_pos + (uint32_t)__shfl(bi, 63, 64);
+
+                const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
+                const bool lfsr_live = st.lfsr != 0;
+
+                // pass 3: plain mantissas, zeros/dither, first members' offsets
+                {
+                    int k = 0, c3 = r3, c5 = r5, c11 = r11, cd = rd0;
+                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
+                    for (int t = t0; t < t1; t++) {
+                        while (t >= L.seg_base[k + 1]) k++;
+                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
+                        const int w = L.bap[ch][bin];
+                        const int e = L.exp[ch][bin];
+                        if (w == -1) { if (c3 % 3 == 0) { L.goff[0][c3 / 3] = (uint16_t)(off - mant_pos); off += 5; } c3++; continue; }
+                        if (w == -2) { if (c5 % 3 == 0) { L.goff[1][c5 / 3] = (uint16_t)(off - mant_pos); off += 7; } c5++; continue; }
+                        if (w == -3) { if ((c11 & 1) == 0) { L.goff[2][c11 >> 1] = (uint16_t)(off - mant_pos); off += 7; } c11++; continue; }
+                        if (ch < 5) {
+                            const float g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
+                            const float fac = sf_of(e) * g;
+                            float v;
+                            if (w == 0) {
+                                if ((dithmask >> ch) & 1) { v = (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0) * fac; cd++; }
+                                else v = 0.f;
+                            } else { v = plain_value(L, w, off) * fac; off += w; }
+                            L.plane[ch][bin] = v;
+                        } else if (ch == 5) {
+                            const float g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+                            const float fac = sf_of(e) * g;
+                            float v = 0.f;
+                            if (w != 0) { v = plain_value(L, w, off) * fac; off += w; }
+                            L.plane[5][bin] = v;
+                        } else {
+                            // coupling channel: parse.c:435-556
+                            const int bnd = L.cplbnd[(bin - st.cplstrtmant) / 12];
+                            float m = 0.f;
+                            if (w != 0) { m = plain_value(L, w, off); off += w; m *= sf_of(e); }
+                            for (int c = 0; c < nf; c++)
+                                if ((st.chincpl >> c) & 1) {
+                                    const float g = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
+                                    const float co = L.cplco[c][bnd] * g;
+                                    float v;
+                                    if (w == 0) {
+                                        if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0); cd++; }
+                                        else v = 0.f;
+                                    } else v = m * co;
+                                    L.plane[c][bin] = v;
+                                }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // pass 4: grouped mantissas
+                {
+                    int k = 0, c3 = r3, c5 = r5, c11 = r11;
+                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
+                    for (int t = t0; t < t1; t++) {
+                        while (t >= L.seg_base[k + 1]) k++;
+                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
+                        const int w = L.bap[ch][bin];
+                        if (w > -1 || w < -3) continue;
+                        float q;
+                        if (w == -1) { q = group_value(L, 0, (int)peek(L.fr, mant_pos + L.goff[0][c3 / 3], 5), c3 % 3); c3++; }
+                        else if (w == -2) { q = group_value(L, 1, (int)peek(L.fr, mant_pos + L.goff[1][c5 / 3], 7), c5 % 3); c5++; }
+                        else { q = group_value(L, 2, (int)peek(L.fr, mant_pos + L.goff[2][c11 >> 1], 7), c11 & 1); c11++; }
+                        const int e = L.exp[ch][bin];
+                        if (ch < 5) {
+                            const float g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
+                            L.plane[ch][bin] = q * (sf_of(e) * g);
+                        } else if (ch == 5) {
+                            const float g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+                            L.plane[5][bin] = q * (sf_of(e) * g);
+                        } else {
+                            const int bnd = L.cplbnd[(bin - st.cplstrtmant) / 12];
+                            const float m = q * sf_of(e);
+                            for (int c = 0; c < nf; c++)
+                                if ((st.chincpl >> c) & 1) {
+                                    const float g = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
+                                    L.plane[c][bin] = m * (L.cplco[c][bnd] * g);
+                                }
+                        }
+                    }
+                }
+                // advance the dither generator past this block's draws
+                if (lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
+
+                // zero tails: parse.c:828-834, 871-872
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    if (c >= nf) continue;
+                    const int from = ((st.chincpl >> c) & 1) ? st.cplendmant : st.endmant[c];
+                    for (int i = from + lane; i < 256; i += 64) L.plane[c][i] = 0.f;
+                }
+                if (st.lfeon) for (int i = 7 + lane; i < 256; i += 64) L.plane[5][i] = 0.f;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // rematrix: parse.c:837-865
+                if (st.acmod == 2 && st.rematflg) {
+                    const int end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
+                    for (int i = 0; i < 4; i++) {
+                        if (!((st.rematflg >> i) & 1)) continue;
+                        const int lo = k_remat_edge[i], hi = k_remat_edge[i + 1] < end ? k_remat_edge[i + 1] : end;
+                        for (int j = lo + lane; j < hi; j += 64) {
+                            const float a = L.plane[0][j], b = L.plane[1][j];
+                            L.plane[0][j] = a + b;
+                            L.plane[1][j] = a - b;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+
+            // ---- write the block's planes (zeros for a failed block) ----
+            if (err) { status |= 1u << blk; frame_dead = true; }
+            {
+                const int in_lfe = P.lfeon ? 1 : 0;
+                for (int c = 0; c < P.n_in; c++) {
+                    const int src_plane = (in_lfe && c == 0) ? 5 : c - in_lfe;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!err) v = *reinterpret_cast<const float4 *>(&L.plane[src_plane][4 * lane]);
+                    *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = v;
+                }
+                if (P.blksw && lane < P.nfchans)
+                    P.blksw[(fidx * 6 + blk) * P.nfchans + lane] = (uint8_t)(err ? 0 : ((blkswm >> lane) & 1));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) P.status[fidx] = status;
+    }
+    if (lane == 0) P.lfsr_state[s] = (uint16_t)st.lfsr;
+}
+
+}  // namespace ac3mi
+
+namespace ac3mi {
+
+hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream)
+{
+    DecodeParams P;
+    P.frames = L.frames;
+    P.coef = L.coef;
+    P.blksw = L.blksw;
+    P.status = L.status;
+    P.lfsr_state = L.lfsr;
+    P.tap_exp = L.tap_exp;
+    P.tap_bap = L.tap_bap;
+    P.lfsr_seq = tab.lfsr_seq;
+    P.lfsr_idx = tab.lfsr_idx;
+    P.tab = tab.dec;
+    P.n_streams = L.n_streams;
+    P.frames_per_stream = L.frames_per_stream;
+    P.frame_stride = L.frame_stride;
+    P.frame_bytes = L.frame_bytes;
+    P.req_flags = L.req_flags;
+    P.level = L.level;
+    P.dynrng_on = L.dynrng_on;
+    P.acmod = L.acmod;
+    P.lfeon = L.lfeon;
+    static const int nfch[8] = {2, 1, 2, 3, 3, 4, 4, 5};
+    P.nfchans = nfch[L.acmod & 7];
+    P.n_in = P.nfchans + (L.lfeon ? 1 : 0);
+    if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_kernel, dim3(L.n_streams), dim3(64), 0, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace ac3mi

@@ -21,6 +21,31 @@ class XformDesc:
         return capi.XformDescC(self.acmod, self.lfeon, self.output, self.bias)
 
 
+@dataclass
+class DecodeDesc:
+    """Arguments of a52_frame() plus the coded configuration a52_syncinfo() reported."""
+    flags: int = 7 | 16
+    level: float = 1.0
+    bias: float = 0.0
+    dynrng: int = 1
+    acmod: int = 7
+    lfeon: int = 1
+    frame_bytes: int = 1536
+
+    def c(self):
+        return capi.DecodeDescC(self.flags, self.level, self.bias, self.dynrng, self.acmod, self.lfeon,
+                                self.frame_bytes)
+
+
+def syncinfo(buf):
+    """a52_syncinfo on host bytes -> (frame_bytes, flags, sample_rate, bit_rate); frame_bytes 0 = no frame."""
+    lib = capi.load_library()
+    b = (ctypes.c_uint8 * 8)(*bytes(buf[:8]))
+    fl, sr, br = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    n = lib.ac3mi_syncinfo(b, ctypes.byref(fl), ctypes.byref(sr), ctypes.byref(br))
+    return n, fl.value, sr.value, br.value
+
+
 class Engine:
     def __init__(self, device=0):
         self.lib = capi.load_library()
@@ -92,3 +117,48 @@ class Engine:
                                                delay.data_ptr(), out.data_ptr(), S, F))
         self._keep.append((coeffs, delay, blksw, out))
         return out
+
+    def decode_planes(self, desc):
+        n_out, fl = ctypes.c_int(), ctypes.c_int()
+        c = desc.c()
+        if self.lib.ac3mi_decode_planes(ctypes.byref(c), ctypes.byref(n_out), ctypes.byref(fl)) != 0:
+            raise capi.AC3MIError("a52_frame would refuse flags %d for acmod %d" % (desc.flags, desc.acmod))
+        return n_out.value, fl.value
+
+    def decode_batch(self, desc, frames, delay, lfsr, out=None, status=None, taps=False, wait_torch=True):
+        """frames [S][F][stride] u8 (stride multiple of 4), delay [S][n_out][128] f32, lfsr [S] i16/u16
+        (both updated in place) -> (pcm [S][F][6][n_out][256] f32, status [S][F] i32[, taps dict])."""
+        import torch
+        if wait_torch:
+            torch.cuda.synchronize(self.device)
+        n_out, out_flags = self.decode_planes(desc)
+        S, F, stride = frames.shape
+        assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.is_cuda
+        assert delay.dtype == torch.float32 and tuple(delay.shape) == (S, n_out, 128) and delay.is_contiguous()
+        assert lfsr.dtype in (torch.int16, torch.uint16) and tuple(lfsr.shape) == (S,)
+        dev = frames.device
+        if out is None:
+            out = torch.empty((S, F, 6, n_out, 256), dtype=torch.float32, device=dev)
+        if status is None:
+            status = torch.zeros((S, F), dtype=torch.int32, device=dev)
+        nf = (2, 1, 2, 3, 3, 4, 4, 5)[desc.acmod]
+        n_in = nf + (1 if desc.lfeon else 0)
+        tp, tdict = None, None
+        if taps:
+            tdict = {
+                "coef": torch.zeros((S, F, 6, n_in, 256), dtype=torch.float32, device=dev),
+                "blksw": torch.zeros((S, F, 6, nf), dtype=torch.uint8, device=dev),
+                "exp": torch.zeros((S, F, 6, 7, 256), dtype=torch.uint8, device=dev),
+                "bap": torch.zeros((S, F, 6, 7, 256), dtype=torch.int8, device=dev),
+            }
+            torch.cuda.synchronize(self.device)
+            tp = capi.DecodeTapsC(tdict["coef"].data_ptr(), tdict["blksw"].data_ptr(), tdict["exp"].data_ptr(),
+                                  tdict["bap"].data_ptr())
+        c = desc.c()
+        self._check(self.lib.ac3mi_decode_batch(self.ctx, ctypes.byref(c), frames.data_ptr(), stride, S, F,
+                                                delay.data_ptr(), lfsr.data_ptr(), out.data_ptr(),
+                                                status.data_ptr(), ctypes.byref(tp) if tp else None))
+        self._keep.append((frames, delay, lfsr, out, status, tdict))
+        if taps:
+            return out, status, tdict
+        return out, status

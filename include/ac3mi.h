@@ -113,6 +113,64 @@ int ac3mi_imdct_batch(ac3mi_ctx *ctx, const ac3mi_xform_desc *desc,
                       float *d_delay, float *d_pcm,
                       int n_streams, int frames_per_stream);
 
+/* ---- frame decode: bitstream -> PCM ------------------------------------------- */
+
+/* Replaces, for a batch of independent streams, the reference's decode inner loop
+ *   a52_syncinfo -> a52_frame -> [a52_dynrng] -> 6 x (a52_block -> a52_samples)
+ * (src/AC3ACM.cpp:1498,1555-1581; a52dec-0.7.5-cvs/src/a52dec.c:270-305), i.e.
+ * L52/parse.c:86-940, L52/bit_allocate.c, L52/bitstream.c/.h, L52/downmix.c, L52/imdct.c.
+ *
+ *  flags   requested output, exactly a52_frame()'s *flags argument
+ *          (channel configuration | AC3MI_LFE | AC3MI_ADJUST_LEVEL)
+ *  level   a52_frame()'s *level argument;  bias: its bias argument
+ *  dynrng  1 = apply the stream's dynamic-range words (liba52's default),
+ *          0 = a52_dynrng(state, NULL, NULL).  A dynrng callback cannot run on the GPU.
+ *  acmod, lfeon, frame_bytes   coded configuration shared by every frame of the batch
+ *          (what a52_syncinfo() reports for any one of them); frames that disagree are
+ *          reported in d_status and produce silence
+ */
+typedef struct {
+    int flags;
+    float level;
+    float bias;
+    int dynrng;
+    int acmod;
+    int lfeon;
+    int frame_bytes;
+} ac3mi_decode_desc;
+
+/* optional per-stage outputs for parity tests; any pointer may be NULL */
+typedef struct {
+    float *d_coef;      /* [S][F][6][n_in][256] dequantised planes handed to the transform */
+    uint8_t *d_blksw;   /* [S][F][6][nfchans] */
+    uint8_t *d_exp;     /* [S][F][6][7][256] exponents after each block: 0-4 fbw, 5 lfe, 6 coupling */
+    int8_t *d_bap;      /* [S][F][6][7][256] bits per mantissa (liba52 convention, L52/bit_allocate.c:49-72) */
+} ac3mi_decode_taps;
+
+/* a52_syncinfo (L52/parse.c:86-129), host side: frame size in bytes, 0 if not a frame */
+int ac3mi_syncinfo(const uint8_t *buf, int *flags, int *sample_rate, int *bit_rate);
+
+/* output planes and granted output flags for a descriptor (a52_downmix_init's table,
+ * L52/downmix.c:37-67); negative when liba52 would refuse the request */
+int ac3mi_decode_planes(const ac3mi_decode_desc *desc, int *n_out, int *out_flags);
+
+/* d_frames  [n_streams][frames_per_stream] frames, frame_stride bytes apart (multiple of 4,
+ *           >= frame_bytes rounded up to 4); base 4-byte aligned
+ * d_delay   [n_streams][n_out][128] overlap tails, read and rewritten (see ac3mi_imdct_batch)
+ * d_lfsr    [n_streams] dither generator state (a52_init sets 1, L52/parse.c:75), read and rewritten
+ * d_pcm     [n_streams][frames_per_stream][6][n_out][256] float, a52_samples() plane order
+ * d_status  [n_streams][frames_per_stream]: bit b (0..5) = a52_block b returned 1 (that block and
+ *           the rest of the frame are silence), bit 8 = a52_syncinfo/a52_frame refused the frame,
+ *           bits 16..23 = output flags a52_frame granted
+ * Exponent / bit-allocation / coupling state is carried from frame to frame inside one call
+ * exactly as a52_state_s does; across calls only d_delay and d_lfsr persist (every valid AC-3
+ * frame re-sends the rest in block 0).
+ */
+int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+                       int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
+                       uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status,
+                       const ac3mi_decode_taps *taps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,9 @@ struct orc_a52 {
     chan_eb cpl, fbw[5], lfe;
 
     float *samples;         /* 12 planes of 256: 0-5 output, 6-11 overlap */
+    float coef_tap[6][256]; /* test tap: dequantised planes (LFE first if output) before synthesis */
+    uint8_t blksw_tap[5];
+    float lfe_tap[256];
     int downmixed;
 };
 
@@ -277,6 +280,11 @@ static chan_eb *tap(orc_a52_t *st, int which)
 }
 void orc_a52_get_exp(orc_a52_t *st, int which, uint8_t *dst) { memcpy(dst, tap(st, which)->exp, 256); }
 void orc_a52_get_bap(orc_a52_t *st, int which, int8_t *dst) { memcpy(dst, tap(st, which)->bap, 256); }
+void orc_a52_get_coefs(orc_a52_t *st, float *dst6x256, uint8_t *blksw5)
+{
+    memcpy(dst6x256, st->coef_tap, sizeof st->coef_tap);
+    memcpy(blksw5, st->blksw_tap, 5);
+}
 int orc_a52_get_lfsr(orc_a52_t *st) { return st->lfsr; }
 void orc_a52_set_lfsr(orc_a52_t *st, int v) { st->lfsr = (uint16_t)v; }
 int orc_a52_get_output(orc_a52_t *st) { return st->output; }
@@ -1601,10 +1609,16 @@ int orc_a52_block(orc_a52_t *st)
         if (st->output & F_LFE) {
             unpack_channel(st, s - 256, &st->lfe, &grp, st->dynrng, 0, 7);
             for (i = 7; i < 256; i++) (s - 256)[i] = 0;
+            memcpy(st->lfe_tap, s - 256, sizeof st->lfe_tap);
             orc_imdct_512(s - 256, s + 1536 - 256, st->bias);
         } else
             unpack_channel(st, s + 1280, &st->lfe, &grp, 0, 0, 7);
     }
+
+    /* test taps (not in the reference): coefficient planes as the transform stage sees them */
+    memcpy(st->coef_tap, st->samples, sizeof st->coef_tap);
+    memcpy(st->blksw_tap, blksw, 5);
+    if (st->lfeon && (st->output & F_LFE)) memcpy(st->coef_tap[0], st->lfe_tap, sizeof st->lfe_tap);
 
     /* ---- synthesis (parse.c:881-937) ---- */
     synth_stage(s, &st->downmixed, st->acmod, st->output, st->bias, st->clev, st->slev, blksw, gain, biasmask);

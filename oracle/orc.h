@@ -38,6 +38,9 @@ void orc_a52_free(orc_a52_t *st);
 /* stage taps: which 0..4 = fbw channel, 5 = lfe, 6 = coupling channel */
 void orc_a52_get_exp(orc_a52_t *st, int which, uint8_t *dst256);
 void orc_a52_get_bap(orc_a52_t *st, int which, int8_t *dst256);
+/* coefficient planes of the last block as the transform stage received them
+ * (plane order of a52_samples: LFE first when output), and the block-switch flags */
+void orc_a52_get_coefs(orc_a52_t *st, float *dst6x256, uint8_t *blksw5);
 int orc_a52_get_lfsr(orc_a52_t *st);
 void orc_a52_set_lfsr(orc_a52_t *st, int v);
 int orc_a52_get_output(orc_a52_t *st);

@@ -1,0 +1,183 @@
+"""GPU parity: ac3mi_decode_batch (HIP front end + transform) vs the liba52 restatement.
+
+Reference behaviour under test: a52_frame + 6 x a52_block (liba52/parse.c:131-940,
+bit_allocate.c, bitstream.c/.h) on frames produced by the encoder oracle.
+ * exponents, bit allocation (bap), block-switch flags: bit-exact (integer stages)
+ * dequantised coefficient planes: bit-exact (built with -ffp-contract=off)
+ * PCM: <= 1e-6 RMS of +-1.0 full scale (north_star tolerance), float32 transform
+ * dither generator state after the call: exact
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import _harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(kind, S, F, seed0=0):
+    """S independent streams of F frames each -> ([S][F][1536] u8 frames, [S] pcm arrays)."""
+    frames = []
+    for s in range(S):
+        pcm = H.gen_pcm(F, 6, seed=seed0 + 1000 * s + 17, kind=kind)
+        frames.append(H.orc_encode(pcm))
+    return np.stack(frames)
+
+
+def _oracle_decode_with_taps(frames, flags, level, bias, dynrng_off=False):
+    """Per stream: oracle decode collecting PCM and the per-block stage taps."""
+    L = H.orc()
+    L.orc_a52_get_coefs.argtypes = [H.vp, H.fp, H.u8p]
+    S, F, fb = frames.shape
+    out = None
+    taps = {"exp": np.zeros((S, F, 6, 7, 256), np.uint8), "bap": np.zeros((S, F, 6, 7, 256), np.int8),
+            "coef": np.zeros((S, F, 6, 6, 256), np.float32), "blksw": np.zeros((S, F, 6, 5), np.uint8)}
+    lfsr = np.zeros(S, np.int64)
+    for s in range(S):
+        st = L.orc_a52_init()
+        buf = np.zeros(F * fb + 64, np.uint8)
+        buf[:F * fb] = frames[s].reshape(-1)
+        for f in range(F):
+            fl, lv = H.ci(flags), H.cf(level)
+            p = ctypes.cast(buf.ctypes.data + f * fb, H.u8p)
+            assert L.orc_a52_frame(st, p, ctypes.byref(fl), ctypes.byref(lv), bias) == 0
+            if dynrng_off:
+                L.orc_a52_dynrng(st, None, None)
+            nout = H.NFCHANS[fl.value & 15] + (1 if fl.value & 16 else 0)
+            if out is None:
+                out = np.zeros((S, F, 6, nout, 256), np.float32)
+            for b in range(6):
+                assert L.orc_a52_block(st) == 0
+                out[s, f, b] = np.ctypeslib.as_array(L.orc_a52_samples(st), (1536,))[:nout * 256].reshape(nout, 256)
+                for w in range(7):
+                    L.orc_a52_get_exp(st, w, H.P(taps["exp"][s, f, b, w], H.u8p))
+                    L.orc_a52_get_bap(st, w, H.P(taps["bap"][s, f, b, w], H.i8p))
+                L.orc_a52_get_coefs(st, H.P(taps["coef"][s, f, b], H.fp), H.P(taps["blksw"][s, f, b], H.u8p))
+        lfsr[s] = L.orc_a52_get_lfsr(st)
+        L.orc_a52_free(st)
+    return out, taps, lfsr, fl.value
+
+
+def _gpu_decode(engine, frames, flags, level, bias, dynrng=1, taps=True):
+    import torch
+    pkg = H.pkg()
+    S, F, fb = frames.shape
+    n, sflags, _, _ = pkg.syncinfo(frames[0, 0])
+    assert n == fb
+    desc = pkg.DecodeDesc(flags=flags, level=level, bias=bias, dynrng=dynrng, acmod=sflags & 7 if (sflags & 15) != 10 else 2,
+                          lfeon=1 if sflags & 16 else 0, frame_bytes=fb)
+    n_out, _ = engine.decode_planes(desc)
+    d_frames = torch.from_numpy(frames).cuda()
+    delay = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
+    lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+    res = engine.decode_batch(desc, d_frames, delay, lfsr, taps=taps)
+    engine.sync()
+    pcm, status = res[0].cpu().numpy(), res[1].cpu().numpy()
+    t = {k: v.cpu().numpy() for k, v in res[2].items()} if taps else None
+    return pcm, status, t, lfsr.cpu().numpy().astype(np.int64) & 0xffff
+
+
+@pytest.mark.parametrize("kind", ["tones", "noise", "quiet", "music"])
+def test_decode_5_1_all_stages(engine, kind):
+    S, F = 6, 3
+    frames = _streams(kind, S, F)
+    ref_pcm, ref_taps, ref_lfsr, ref_flags = _oracle_decode_with_taps(frames, 7 | 16, 1.0, 0.0)
+    pcm, status, taps, lfsr = _gpu_decode(engine, frames, 7 | 16, 1.0, 0.0)
+    assert (status & 0x1ff).max() == 0, status
+    assert ((status >> 16) & 0xff == ref_flags).all()
+    # integer stages: bit-exact.  slots 0-4 fbw (223 bins), 5 lfe (7 bins); no coupling in these streams
+    for w, n in [(0, 223), (1, 223), (2, 223), (3, 223), (4, 223), (5, 7)]:
+        assert np.array_equal(taps["exp"][:, :, :, w, :n], ref_taps["exp"][:, :, :, w, :n]), "exp ch %d" % w
+        assert np.array_equal(taps["bap"][:, :, :, w, :n], ref_taps["bap"][:, :, :, w, :n]), "bap ch %d" % w
+    assert np.array_equal(taps["blksw"], ref_taps["blksw"])
+    # dequantised planes: same bits (LFE first in both layouts for 5.1 output)
+    assert np.array_equal(taps["coef"].view(np.uint32), ref_taps["coef"].view(np.uint32)), "coefficients differ"
+    # dither generator advanced identically
+    assert np.array_equal(lfsr, ref_lfsr)
+    err = pcm.astype(np.float64) - ref_pcm
+    assert H.rms(err) <= 1e-6 and np.abs(err).max() <= 4e-6, (H.rms(err), np.abs(err).max())
+
+
+@pytest.mark.parametrize("flags,level,bias", [(2, 1.0, 0.0), (2 | 32, 1.0, 0.0), (10, 1.0, 0.0), (1 | 32, 0.5, 0.0),
+                                               (3, 1.0, 0.0), (4 | 16, 1.0, 0.0), (5 | 32, 1.0, 0.0),
+                                               (6 | 16 | 32, 2.0, 0.0), (7, 1.0, 0.0), (7 | 16 | 32, 1.0, 384.0)])
+def test_decode_output_modes(engine, flags, level, bias):
+    """Every output request the ACM driver or a52dec can make for a 5.1 stream
+    (src/AC3ACM.cpp:1520-1553), incl. A52_ADJUST_LEVEL and the driver's bias 384."""
+    S, F = 4, 2
+    frames = _streams("tones", S, F, seed0=flags)
+    ref_pcm, ref_taps, _, ref_flags = _oracle_decode_with_taps(frames, flags, level, bias)
+    pcm, status, taps, _ = _gpu_decode(engine, frames, flags, level, bias)
+    assert (status & 0x1ff).max() == 0
+    assert ((status >> 16) & 0xff == ref_flags).all(), (status >> 16, ref_flags)
+    # coefficient planes carry the per-channel downmix gains: compare bit for bit
+    lfe_out = 1 if ref_flags & 16 else 0
+    got = taps["coef"]                                   # [.., 6 planes: LFE, L, C, R, SL, SR]
+    want = ref_taps["coef"]                              # liba52 layout: LFE first only when output
+    assert np.array_equal(got[:, :, :, 1:6].view(np.uint32), want[:, :, :, lfe_out:lfe_out + 5].view(np.uint32))
+    if lfe_out:
+        assert np.array_equal(got[:, :, :, 0].view(np.uint32), want[:, :, :, 0].view(np.uint32))
+    err = pcm.astype(np.float64) - ref_pcm
+    tol = 1e-6 if bias == 0 else 4e-5                   # at bias 384 one float32 ulp is 3.05e-5
+    assert H.rms(err) <= tol and np.abs(err).max() <= 4 * tol, (H.rms(err), np.abs(err).max())
+
+
+def test_dynrng_off_and_long_stream(engine):
+    """a52_dynrng(state, NULL, NULL) (src/AC3ACM.cpp:2047-2050) and a longer stream: the dither
+    LFSR, csnroffst carry-over in the encoder and the overlap tails all thread through 12 frames."""
+    frames = _streams("tones", 2, 12, seed0=5)
+    ref_pcm, _, ref_lfsr, _ = _oracle_decode_with_taps(frames, 7 | 16, 1.0, 0.0, dynrng_off=True)
+    pcm, status, _, lfsr = _gpu_decode(engine, frames, 7 | 16, 1.0, 0.0, dynrng=0, taps=False)
+    assert (status & 0x1ff).max() == 0
+    assert np.array_equal(lfsr, ref_lfsr)
+    err = pcm.astype(np.float64) - ref_pcm
+    assert H.rms(err) <= 1e-6, H.rms(err)
+
+
+def test_corrupt_and_foreign_frames_are_flagged(engine):
+    """Frames liba52 refuses: bad sync word (a52_syncinfo returns 0, parse.c:100-101) and a frame of
+    another configuration inside the batch.  They must be reported, decode to silence, and must not
+    disturb their neighbours."""
+    frames = _streams("tones", 3, 2, seed0=9)
+    bad = frames.copy()
+    bad[1, 0, 0] = 0x0c                                  # stream 1 frame 0: sync word broken
+    bad[2, 1, 6] = (bad[2, 1, 6] & 0x1f) | (2 << 5)      # stream 2 frame 1: acmod field says 2.0
+    pcm, status, _, _ = _gpu_decode(engine, bad, 7 | 16, 1.0, 0.0, taps=False)
+    ref_pcm, _, _, _ = _oracle_decode_with_taps(frames[:1], 7 | 16, 1.0, 0.0)
+    assert status[0].tolist() == [23 << 16, 23 << 16]
+    assert status[1, 0] & 0x100 and status[2, 1] & 0x100
+    assert status[1, 1] & 0x1ff == 0 and status[2, 0] & 0x1ff == 0
+    assert H.rms(pcm[0].astype(np.float64) - ref_pcm[0]) <= 1e-6
+    assert np.abs(pcm[1, 0]).max() == 0.0                # refused frame + zero history -> silence
+
+
+def test_exponent_error_is_reported(engine):
+    """A reserved exponent-group code (>= 125) makes a52_block return 1 (parse.c:227-228 via
+    tables.h exp_1[125..127] = 25).  Block 0 of a 5.1 frame from this encoder starts its first
+    exponent group at a fixed position, so overwrite it with 127."""
+    frames = _streams("tones", 1, 1, seed0=11)
+    L = H.orc()
+    st = L.orc_a52_init()
+    buf = np.zeros(1600, np.uint8)
+    buf[:1536] = frames[0, 0]
+    fl, lv = H.ci(23), H.cf(1.0)
+    L.orc_a52_frame(st, H.P(buf, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0)
+    hdr_bits = L.orc_a52_bitpos(st)
+    L.orc_a52_free(st)
+    # block 0 side info of this encoder: 5 blksw, 5 dith, dynrnge, cplstre, cplinu, 5x2 chexpstr,
+    # lfeexpstr, 5 x chbwcod(6) -> then channel 0: 4-bit absolute exponent, then the first 7-bit group
+    pos = hdr_bits + 5 + 5 + 1 + 2 + 10 + 1 + 30 + 4
+    bits = np.unpackbits(frames[0, 0])
+    bits[pos:pos + 7] = 1
+    bad = np.packbits(bits).reshape(1, 1, 1536)
+    pcm, status, _, _ = _gpu_decode(engine, bad, 7 | 16, 1.0, 0.0, taps=False)
+    assert status[0, 0] & 0x3f == 0x3f and not (status[0, 0] & 0x100)
+    # the oracle agrees that block 0 fails
+    st = L.orc_a52_init()
+    buf[:1536] = bad[0, 0]
+    fl, lv = H.ci(23), H.cf(1.0)
+    assert L.orc_a52_frame(st, H.P(buf, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0) == 0
+    assert L.orc_a52_block(st) == 1
+    L.orc_a52_free(st)
