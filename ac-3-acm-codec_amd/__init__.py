@@ -12,3 +12,4 @@ The directory name contains hyphens, so import it with
 from .capi import LIB_PATH, load_library, declared_symbols, AC3MIError  # noqa: F401
 from .engine import Engine, XformDesc, DecodeDesc, syncinfo  # noqa: F401
 from . import flags  # noqa: F401
+from . import sharding  # noqa: F401

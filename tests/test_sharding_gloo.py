@@ -1,0 +1,74 @@
+"""CPU, world_size 2 over gloo: the N>1 layout used by bench.py - contiguous stream shards, no
+data-path collective, MAX-reduced timing, SUM-reduced frame counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import _harness as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_streams, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = H.pkg().sharding
+    lo, hi = sh.shard(n_streams, world, rank)
+    # each rank "processes" its own streams: here the CPU oracle transform on a tiny batch
+    rng = np.random.default_rng(1234)
+    coef = (rng.standard_normal((n_streams, 1, 6, 6, 256)) * 0.05).astype(np.float32)
+    pcm, _ = H.orc_xform(coef[lo:hi], None, 7, 1, 7 | 16)
+    t = 0.010 * (rank + 1)
+    tmax, = sh.reduce_max([t], dist)
+    total, = sh.reduce_sum([hi - lo], dist)
+    dist.barrier()
+    q.put((rank, lo, hi, tmax, total, float(np.abs(pcm).sum())))
+    dist.destroy_process_group()
+
+
+def test_shards_cover_all_streams_without_overlap():
+    sh = H.pkg().sharding
+    for n in (0, 1, 7, 8, 65536, 8_000_000, 8_000_003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [sh.shard(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_gloo():
+    import importlib
+    H.pkg()                                       # make sure the package (and .sharding) imports in the parent
+    importlib.import_module("ac-3-acm-codec_amd.sharding")
+    world, n_streams = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 5)]
+    assert all(abs(r[3] - 0.020) < 1e-12 for r in res)          # MAX over ranks
+    assert all(r[4] == n_streams for r in res)                  # SUM of per-rank work = whole job
+    # sharded result == unsharded result (streams are independent)
+    rng = np.random.default_rng(1234)
+    coef = (rng.standard_normal((n_streams, 1, 6, 6, 256)) * 0.05).astype(np.float32)
+    pcm, _ = H.orc_xform(coef, None, 7, 1, 7 | 16)
+    assert abs(sum(r[5] for r in res) - float(np.abs(pcm).sum())) < 1e-3
