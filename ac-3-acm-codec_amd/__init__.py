@@ -10,6 +10,6 @@ The directory name contains hyphens, so import it with
 ``importlib.import_module("ac-3-acm-codec_amd")``.
 """
 from .capi import LIB_PATH, load_library, declared_symbols, AC3MIError  # noqa: F401
-from .engine import Engine, XformDesc, DecodeDesc, syncinfo  # noqa: F401
+from .engine import Engine, XformDesc, DecodeDesc, EncodeDesc, syncinfo  # noqa: F401
 from . import flags  # noqa: F401
 from . import sharding  # noqa: F401

@@ -28,6 +28,16 @@ class DecodeTapsC(ctypes.Structure):
     _fields_ = [("d_coef", c_void_p), ("d_blksw", c_void_p), ("d_exp", c_void_p), ("d_bap", c_void_p)]
 
 
+class EncodeDescC(ctypes.Structure):
+    _fields_ = [("sample_rate", c_int), ("bit_rate", c_int), ("channels", c_int)]
+
+
+class EncodeTapsC(ctypes.Structure):
+    _fields_ = [("d_mdct", c_void_p), ("d_exponent", c_void_p), ("d_exp_samples", c_void_p),
+                ("d_encoded_exp", c_void_p), ("d_bap", c_void_p), ("d_exp_strategy", c_void_p),
+                ("d_snroffst", c_void_p)]
+
+
 _lib = None
 
 
@@ -85,5 +95,9 @@ def load_library():
     lib.ac3mi_decode_planes.argtypes = [ctypes.POINTER(DecodeDescC), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.ac3mi_decode_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecodeTapsC)]
+    lib.ac3mi_encode_frame_bytes.argtypes = [ctypes.POINTER(EncodeDescC)]
+    lib.ac3mi_encode_tables.argtypes = [c_void_p] * 5
+    lib.ac3mi_encode_batch.argtypes = [c_void_p, ctypes.POINTER(EncodeDescC), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, ctypes.POINTER(EncodeTapsC)]
     _lib = lib
     return lib

@@ -16,6 +16,26 @@ struct DecTables {
     float qlev[48];     // [0,3) 3-level  [3,8) 5-level  [8,16) 7-level  [16,27) 11-level  [27,43) 15-level
 };
 
+// encoder tables (device copy): ENC/ac3tab.h + the runtime tables of AC3_encode_init
+struct EncTables {
+    int16_t win[256];           // ac3_window, Q15
+    int16_t cos[64], sin[64];   // costab / sintab (fft_init(7))
+    int16_t xcos[128], xsin[128];
+    uint8_t bitrev[128];
+    uint8_t latab[256];
+    uint16_t hth[50][3];
+    uint8_t baptab[64];
+    uint8_t band_of_bin[256];   // masktab
+    uint8_t band_start[51];     // bndtab (entry 50 = 0 as in ac3_common_init)
+    uint8_t band_size[50];      // bndsz
+    uint16_t crc_tab[256];
+};
+
+// what AC3_encode_init derives from (freq, bitrate, channels): ENC/ac3enc.cpp:1019-1110
+struct EncConfig {
+    int nch, nfbw, lfe, acmod, fscod, halfrate, bsid, frmsizecod, frame_words;
+};
+
 // Device-resident constant tables, built on the host in double precision.
 struct DeviceTables {
     float2 *tw_long;    // [8][16]  merged lane twiddles, long block
@@ -24,6 +44,7 @@ struct DeviceTables {
     DecTables *dec;     // bit-allocation / dequantiser tables
     uint16_t *lfsr_seq; // [65535] dither LFSR states in cycle order from state 1 (L52/parse.c:310-319)
     uint16_t *lfsr_idx; // [65536] inverse: position of a state in the cycle
+    EncTables *enc;
 };
 
 struct MixPlan {
@@ -63,6 +84,25 @@ struct DecodeLaunch {
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 void build_dec_tables(DecTables *t, uint16_t *lfsr_seq /*[65535]*/, uint16_t *lfsr_idx /*[65536]*/);
 
+struct EncodeLaunch {
+    EncConfig cfg;
+    const int16_t *pcm;         // [S][F][1536][nch]
+    int16_t *last;              // [S][nch][256]
+    int32_t *csnr;              // [S]
+    uint8_t *frames;            // [S][F][stride]
+    int frame_stride, n_streams, frames_per_stream;
+    uint8_t chmap[8];
+    int32_t *ws_mdct;           // [S][F][6][nch][256]
+    uint8_t *ws_expo;           // [S][F][6][nch][256]
+    int8_t *ws_shift;           // [S][F][6][nch]
+    uint8_t *tap_eexp, *tap_bap, *tap_strat;
+    int32_t *tap_snr;
+};
+hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStream_t stream);
+hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream);
+void build_enc_tables(EncTables *t);
+int enc_config(int freq, int bitrate, int channels, EncConfig *c);   // 0 = rejected (AC3_encode_init returns 0)
+
 void build_host_tables(float *window256, float2 *tw_long /*[8][16]*/, float2 *tw_short /*[8][16]*/);
 
 }  // namespace ac3mi
@@ -76,5 +116,8 @@ struct ac3mi_ctx {
     float *ws_coef;
     uint8_t *ws_blksw;
     size_t ws_coef_bytes, ws_blksw_bytes;
+    // encode workspace (MDCT coefficients, exponents, block exponents between the two kernels)
+    void *ws_enc;
+    size_t ws_enc_bytes;
     std::string err;
 };

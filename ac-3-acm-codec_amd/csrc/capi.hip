@@ -89,6 +89,102 @@ void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
     }
 }
 
+// encoder tables: ENC/ac3tab.h and AC3_encode_init (ENC/ac3enc.cpp:977-1016, 1094-1104)
+static int16_t fix15(float a)                        // ENC/ac3enc.cpp:428-439
+{
+    int v = (int)(a * (float)(1 << 15));
+    if (v < -32767) v = -32767; else if (v > 32767) v = 32767;
+    return (int16_t)v;
+}
+
+void build_enc_tables(EncTables *t)
+{
+    const double pi = 3.14159265358979323846;
+    // ac3_window (ENC/ac3tab.h:15-48) = floor(32768 * KBD alpha-5 window)
+    double acc = 0, cum[256];
+    for (int i = 0; i < 256; i++) {
+        acc += bessel_i0(i * (256 - i) * (5 * pi / 256) * (5 * pi / 256));
+        cum[i] = acc;
+    }
+    acc += 1;
+    for (int i = 0; i < 256; i++) t->win[i] = (int16_t)floor(32768.0 * sqrt(cum[i] / acc));
+    // fft_init(7): cos/sin of a float argument -> float overloads in the reference's C++ unit (:441-459)
+    for (int i = 0; i < 64; i++) {
+        float alpha = (float)(2 * pi * (float)i / (float)128);
+        t->cos[i] = fix15(cosf(alpha));
+        t->sin[i] = fix15(sinf(alpha));
+    }
+    for (int i = 0; i < 128; i++) {
+        int m = 0;
+        for (int j = 0; j < 7; j++) m |= ((i >> j) & 1) << (6 - j);
+        t->bitrev[i] = (uint8_t)m;
+        float alpha = (float)(2 * pi * (i + 1.0 / 8.0) / (float)512);      // :1098-1102
+        t->xcos[i] = fix15(-cosf(alpha));
+        t->xsin[i] = fix15(-sinf(alpha));
+    }
+    build_logadd(t->latab);
+    for (int b = 0; b < 50; b++)
+        for (int f = 0; f < 3; f++) t->hth[b][f] = (uint16_t)(0xc00 - kHth[f][b]);
+    // baptab: address (psd - mask) >> 5 -> bap code; same table as the decoder's widths, as codes
+    for (int a = 0; a < 64; a++) {
+        const int w = kWidth[63 - a];
+        int code;
+        switch (w) {
+        case 0: code = 0; break;
+        case -1: code = 1; break;
+        case -2: code = 2; break;
+        case 3: code = 3; break;
+        case -3: code = 4; break;
+        case 4: code = 5; break;
+        case 14: code = 14; break;
+        case 16: code = 15; break;
+        default: code = w + 1; break;       // widths 5..12 -> codes 6..13
+        }
+        t->baptab[a] = (uint8_t)code;
+    }
+    // band structure: bins 0..27 are 1-wide, then kBandEnd
+    int start = 0, k = 0;
+    for (int b = 0; b < 50; b++) {
+        const int end = b < 20 ? b + 1 : kBandEnd[b - 20];
+        t->band_start[b] = (uint8_t)start;
+        t->band_size[b] = (uint8_t)(end - start);
+        for (; k < end; k++) t->band_of_bin[k] = (uint8_t)b;
+        start = end;
+    }
+    for (; k < 256; k++) t->band_of_bin[k] = 49;
+    t->band_start[50] = 0;
+    for (int n = 0; n < 256; n++) {                                          // ac3_crc_init :998-1016
+        unsigned c = (unsigned)n << 8;
+        for (int j = 0; j < 8; j++) c = (c & 0x8000) ? (((c << 1) & 0xffff) ^ 0x8005) : (c << 1);
+        t->crc_tab[n] = (uint16_t)c;
+    }
+}
+
+int enc_config(int freq, int bitrate, int channels, EncConfig *c)
+{
+    static const uint8_t acmod_of[6] = {1, 2, 3, 6, 7, 7};
+    static const int rates[3] = {48000, 44100, 32000};
+    static const int kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
+    if (channels < 1 || channels > 6) return 0;
+    c->nch = channels;
+    c->acmod = acmod_of[channels - 1];
+    c->lfe = channels == 6;
+    c->nfbw = channels > 5 ? 5 : channels;
+    bool found = false;
+    for (int i = 0; i < 3 && !found; i++)
+        for (int j = 0; j < 3; j++)
+            if ((rates[j] >> i) == freq) { c->halfrate = i; c->fscod = j; found = true; break; }
+    if (!found) return 0;
+    c->bsid = 8 + c->halfrate;
+    bitrate /= 1000;
+    int i;
+    for (i = 0; i < 19; i++) if ((kbps[i] >> c->halfrate) == bitrate) break;
+    if (i == 19) return 0;
+    c->frmsizecod = i << 1;
+    c->frame_words = (bitrate * 1000 * 1536) / (freq * 16);
+    return c->frame_words * 2;
+}
+
 // ---------------------------------------------------------------------------
 // a52_downmix() as a plane-mixing matrix (L52/downmix.c:480-619) and the set of
 // outputs a52_downmix_init() can grant (L52/downmix.c:37-67)
@@ -239,6 +335,12 @@ static int ctx_init(ac3mi_ctx *ctx)
         HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_seq, seq.data(), 65535 * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_idx, idx.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
+    {
+        EncTables et;
+        build_enc_tables(&et);
+        HIPCHK(ctx, hipMalloc(&ctx->tab.enc, sizeof et));
+        HIPCHK(ctx, hipMemcpy(ctx->tab.enc, &et, sizeof et, hipMemcpyHostToDevice));
+    }
     return AC3MI_OK;
 }
 
@@ -256,7 +358,9 @@ ac3mi_ctx *ac3mi_create(int device)
     ac3mi_ctx *ctx = new ac3mi_ctx();
     ctx->device = device;
     ctx->stream = nullptr;
-    ctx->tab = DeviceTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ctx->tab = DeviceTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ctx->ws_enc = nullptr;
+    ctx->ws_enc_bytes = 0;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
     ctx->ws_coef_bytes = ctx->ws_blksw_bytes = 0;
@@ -281,6 +385,8 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->tab.lfsr_idx);
     (void)hipFree(ctx->ws_coef);
     (void)hipFree(ctx->ws_blksw);
+    (void)hipFree(ctx->ws_enc);
+    (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -441,6 +547,8 @@ static int ensure_ws(ac3mi_ctx *ctx, size_t coef_bytes, size_t blksw_bytes)
     if (blksw_bytes > ctx->ws_blksw_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_blksw);
+    (void)hipFree(ctx->ws_enc);
+    (void)hipFree(ctx->tab.enc);
         ctx->ws_blksw = nullptr;
         ctx->ws_blksw_bytes = 0;
         HIPCHK(ctx, hipMalloc(&ctx->ws_blksw, blksw_bytes));
@@ -509,6 +617,86 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     X.frames = frames_per_stream;
     X.bias = desc->bias;
     HIPCHK(ctx, launch_xform(ctx->tab, X, ctx->stream));
+    return AC3MI_OK;
+}
+
+int ac3mi_encode_frame_bytes(const ac3mi_encode_desc *desc)
+{
+    EncConfig c;
+    if (!desc) return 0;
+    return enc_config(desc->sample_rate, desc->bit_rate, desc->channels, &c);
+}
+
+int ac3mi_encode_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128, int16_t *window256)
+{
+    EncTables et;
+    build_enc_tables(&et);
+    if (costab64) memcpy(costab64, et.cos, sizeof et.cos);
+    if (sintab64) memcpy(sintab64, et.sin, sizeof et.sin);
+    if (xcos128) memcpy(xcos128, et.xcos, sizeof et.xcos);
+    if (xsin128) memcpy(xsin128, et.xsin, sizeof et.xsin);
+    if (window256) memcpy(window256, et.win, sizeof et.win);
+    return AC3MI_OK;
+}
+
+int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int16_t *d_pcm, const uint8_t *chmap,
+                       int16_t *d_last, int32_t *d_csnroffst, uint8_t *d_frames, int frame_stride, int n_streams,
+                       int frames_per_stream, const ac3mi_encode_taps *taps)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    EncodeLaunch E;
+    if (!desc || !d_pcm || !chmap || !d_last || !d_csnroffst || !d_frames || n_streams < 0 || frames_per_stream < 0) {
+        ctx->err = "ac3mi_encode_batch: bad argument";
+        return AC3MI_ERR_ARG;
+    }
+    const int fb = enc_config(desc->sample_rate, desc->bit_rate, desc->channels, &E.cfg);
+    if (fb <= 0) {
+        ctx->err = "ac3mi_encode_batch: AC3_encode_init would return 0 for this rate/bitrate/channels";
+        return AC3MI_ERR_ARG;
+    }
+    if (frame_stride < ((fb + 3) & ~3) || (frame_stride & 3) || ((uintptr_t)d_frames & 3) || ((uintptr_t)d_pcm & 1)) {
+        ctx->err = "ac3mi_encode_batch: frame_stride must be a multiple of 4 and >= the frame size";
+        return AC3MI_ERR_ARG;
+    }
+    for (int i = 0; i < 8; i++) E.chmap[i] = i < desc->channels ? chmap[i] : 0;
+    for (int i = 0; i < desc->channels; i++)
+        if (E.chmap[i] >= desc->channels) {
+            ctx->err = "ac3mi_encode_batch: chmap entry out of range";
+            return AC3MI_ERR_ARG;
+        }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t rows = (size_t)n_streams * frames_per_stream * 6 * E.cfg.nch;
+    const size_t need = rows * 256 * 4 + rows * 256 + ((rows + 255) & ~(size_t)255) + 1024;
+    if (need > ctx->ws_enc_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws_enc);
+        ctx->ws_enc = nullptr;
+        ctx->ws_enc_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_enc, need));
+        ctx->ws_enc_bytes = need;
+    }
+    E.ws_mdct = (int32_t *)ctx->ws_enc;
+    E.ws_expo = (uint8_t *)ctx->ws_enc + rows * 256 * 4;
+    E.ws_shift = (int8_t *)ctx->ws_enc + rows * 256 * 4 + rows * 256;
+    if (taps && taps->d_mdct) E.ws_mdct = taps->d_mdct;
+    if (taps && taps->d_exponent) E.ws_expo = taps->d_exponent;
+    if (taps && taps->d_exp_samples) E.ws_shift = taps->d_exp_samples;
+    E.pcm = d_pcm;
+    E.last = d_last;
+    E.csnr = d_csnroffst;
+    E.frames = d_frames;
+    E.frame_stride = frame_stride;
+    E.n_streams = n_streams;
+    E.frames_per_stream = frames_per_stream;
+    E.tap_eexp = taps ? taps->d_encoded_exp : nullptr;
+    E.tap_bap = taps ? taps->d_bap : nullptr;
+    E.tap_strat = taps ? taps->d_exp_strategy : nullptr;
+    E.tap_snr = taps ? taps->d_snroffst : nullptr;
+    if ((E.tap_bap == nullptr) != (E.tap_eexp == nullptr)) {
+        ctx->err = "ac3mi_encode_batch: d_bap and d_encoded_exp taps must be given together";
+        return AC3MI_ERR_ARG;
+    }
+    HIPCHK(ctx, launch_encode(ctx->tab, E, ctx->stream));
     return AC3MI_OK;
 }
 

@@ -1,0 +1,899 @@
+// encode.hip — AC-3 encoder on gfx950, bit-exact restatement of ENC/ac3enc.cpp
+// (AC3_encode_frame, :1640-1763) in two kernels.
+//
+//  enc_mdct_kernel   one wavefront per (stream, frame, channel): gather/deinterleave via chmap,
+//                    Q15 window, block-floating-point normalisation, the reference's 16-bit
+//                    radix-2 DIT FFT (one butterfly per lane per pass, data in LDS so that every
+//                    butterfly has exactly the reference's operands, shifts and int16 stores),
+//                    post-rotation, exponent extraction.            [ac3enc.cpp:1665-1722, 462-603]
+//  enc_pack_kernel   one wavefront per stream, frames in order (the SNR-offset search starts from
+//                    the previous frame's csnroffst): exponent strategy, min-merge and constraint
+//                    (closed form: min over j of g[j] + 2|i-j|), PSD/excitation/mask once per
+//                    (block, channel) on one lane each, the reference's exact search sequence with
+//                    every candidate evaluated by a wavefront-wide histogram reduction,
+//                    quantisation, grouped-mantissa assembly with LDS atomics, bit packing with
+//                    prefix-summed offsets, both CRCs by per-lane chunk CRC + GF(2) combine.
+//                                                                      [ac3enc.cpp:606-975, 1113-1638]
+//
+// Integer arithmetic only (no -ffast-math dependence); the Q15 tables come from the host (capi.hip)
+// with the reference's expressions.
+#include "ac3mi_internal.h"
+
+namespace ac3mi {
+
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__device__ __forceinline__ int ilog2u(unsigned v) { return v ? 31 - __builtin_clz(v) : 0; }   // av_log2, :1539-1567
+
+__device__ __forceinline__ int wave_or(int v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
+{
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 1: window + normalise + MDCT + exponents
+
+struct MdctParams {
+    const int16_t *pcm;         // [S][F][1536][nch] interleaved
+    int16_t *last;              // [S][nch][256] history before frame 0 (read only here)
+    int32_t *mdct;              // [S][F][6][nch][256]
+    uint8_t *expo;              // [S][F][6][nch][256]
+    int8_t *shift;              // [S][F][6][nch]
+    const EncTables *tab;
+    int n_streams, frames, nch;
+    uint8_t chmap[8];
+};
+
+struct c16 { int16_t re, im; };
+
+__device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int ay)
+{
+    p.re = (int16_t)((bx + ax) >> 1);
+    p.im = (int16_t)((by + ay) >> 1);
+    q.re = (int16_t)((bx - ax) >> 1);
+    q.im = (int16_t)((by - ay) >> 1);
+}
+
+__global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
+{
+    __shared__ int16_t in[512];
+    __shared__ c16 z[128];
+    __shared__ int32_t out[256];
+    __shared__ int16_t win[256], xc[128], xs[128], ct[64], sn[64];
+    __shared__ uint8_t rev[128];
+
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;                    // (s*F + f)*nch + ch
+    const int ch = unit % P.nch;
+    const int sf = unit / P.nch;
+    const int f = sf % P.frames;
+    const int s = sf / P.frames;
+
+    for (int i = lane; i < 256; i += 64) win[i] = P.tab->win[i];
+    for (int i = lane; i < 128; i += 64) { xc[i] = P.tab->xcos[i]; xs[i] = P.tab->xsin[i]; rev[i] = P.tab->bitrev[i]; }
+    ct[lane] = P.tab->cos[lane];
+    sn[lane] = P.tab->sin[lane];
+
+    const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
+    for (int blk = 0; blk < 6; blk++) {
+        // ---- 512 input samples: 256 old + 256 new (:1673-1683) ----
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            int16_t oldv;
+            if (blk > 0) oldv = frame_pcm[(size_t)((blk - 1) * 256 + j) * P.nch];
+            else if (f > 0) oldv = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];      // block 5 of the previous frame
+            else oldv = P.last[((size_t)s * P.nch + ch) * 256 + j];
+            const int16_t newv = frame_pcm[(size_t)(blk * 256 + j) * P.nch];
+            // window (:1686-1693)
+            in[j] = (int16_t)((oldv * win[j]) >> 15);
+            in[256 + j] = (int16_t)((newv * win[255 - j]) >> 15);
+        }
+        WAVE_SYNC();
+        // ---- block floating point (:1697-1700) ----
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = in[lane + 64 * k];
+            acc |= v < 0 ? -v : v;
+        }
+        acc = wave_or(acc);
+        int v = 14 - ilog2u((unsigned)acc);
+        if (v < 0) v = 0;
+        const int shift = v - 9;
+        if (v > 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(in[lane + 64 * k] * (1 << v));
+        }
+        WAVE_SYNC();
+        // ---- rotation + pre-rotation (:578-591), stored bit-reversed (:496-504) ----
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = lane + 64 * k;
+            auto rot = [&](int t) -> int { return t < 128 ? (int)(int16_t)(-in[t + 384]) : (int)in[t - 128]; };
+            const int re = (rot(2 * i) - rot(511 - 2 * i)) >> 1;
+            const int im = (-(rot(256 + 2 * i) - rot(255 - 2 * i))) >> 1;
+            const int c = -xc[i], sx = xs[i];
+            c16 t;
+            t.re = (int16_t)((re * c - im * sx) >> 15);
+            t.im = (int16_t)((re * sx + c * im) >> 15);
+            z[rev[i]] = t;
+        }
+        WAVE_SYNC();
+        // ---- pass 0 (:508-515) ----
+        {
+            c16 p = z[2 * lane], q = z[2 * lane + 1];
+            bfly(p, q, p.re, p.im, q.re, q.im);
+            z[2 * lane] = p;
+            z[2 * lane + 1] = q;
+        }
+        WAVE_SYNC();
+        // ---- pass 1 (:519-529): twiddles 1 and -j ----
+        {
+            const int base = 4 * (lane >> 1) + (lane & 1);
+            c16 p = z[base], q = z[base + 2];
+            if (lane & 1) bfly(p, q, p.re, p.im, q.im, -q.re);
+            else bfly(p, q, p.re, p.im, q.re, q.im);
+            z[base] = p;
+            z[base + 2] = q;
+        }
+        WAVE_SYNC();
+        // ---- passes 2..6 (:533-567) ----
+        for (int nloops = 4, nblocks = 16; nblocks; nloops <<= 1, nblocks >>= 1) {
+            const int j = lane / nloops, m = lane - j * nloops;
+            const int ip = j * 2 * nloops + m, iq = ip + nloops;
+            c16 p = z[ip], q = z[iq];
+            if (m == 0) bfly(p, q, p.re, p.im, q.re, q.im);
+            else {
+                const int l = m * nblocks;
+                const int c = ct[l], sx = -sn[l];
+                const int tr = (c * q.re - sx * q.im) >> 15;
+                const int ti = (c * q.im + q.re * sx) >> 15;
+                bfly(p, q, p.re, p.im, tr, ti);
+            }
+            z[ip] = p;
+            z[iq] = q;
+            WAVE_SYNC();
+        }
+        // ---- post-rotation (:596-602) ----
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = lane + 64 * k;
+            const int re = z[i].re, im = z[i].im, sx = xs[i], c = xc[i];
+            out[2 * i] = (re * c + sx * im) >> 15;
+            out[255 - 2 * i] = (re * sx - im * c) >> 15;
+        }
+        WAVE_SYNC();
+        // ---- exponents (:1707-1722) ----
+        const size_t row = (((size_t)s * P.frames + f) * 6 + blk) * P.nch + ch;
+        int4 cv = *reinterpret_cast<const int4 *>(&out[4 * lane]);
+        int cc[4] = {cv.x, cv.y, cv.z, cv.w};
+        uint32_t epack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = cc[k] < 0 ? -cc[k] : cc[k];
+            int e;
+            if (a == 0) e = 24;
+            else {
+                e = 23 - ilog2u((unsigned)a) + shift;
+                if (e >= 24) { e = 24; cc[k] = 0; }
+            }
+            epack |= (uint32_t)(e & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
+        *reinterpret_cast<uint32_t *>(P.expo + row * 256 + 4 * lane) = epack;
+        if (lane == 0) P.shift[row] = (int8_t)shift;
+        WAVE_SYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 2: exponent coding, bit allocation, quantisation, packing
+
+struct PackParams {
+    const int32_t *mdct;
+    const uint8_t *expo;
+    const int8_t *shift;
+    int32_t *csnr_state;        // [S] in/out
+    uint8_t *frames;            // [S][F][stride]
+    const EncTables *tab;
+    // taps (optional)
+    uint8_t *tap_eexp;          // [S][F][6][nch][256]
+    uint8_t *tap_bap;           // [S][F][6][nch][256]
+    uint8_t *tap_strat;         // [S][F][6][nch]
+    int32_t *tap_snr;           // [S][F][2]
+    int n_streams, frames_per_stream, frame_stride;
+    int nch, nfbw, lfe, acmod, fscod, halfrate, bsid, frmsizecod, frame_words;
+    int nbc;                    // coefficients per full-bandwidth channel (223)
+    int chbwcod;
+    uint32_t crc_inv;           // x^-(16*fs58-16) mod poly (:1627)
+    uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
+    int c1, c2;                 // CRC chunk bytes per lane
+};
+
+constexpr int PK_MAXBYTES = 3840 + 256;
+constexpr int PK_FRW = PK_MAXBYTES / 4;
+
+struct PackLDS {
+    uint8_t E[36][256];         // exponents, raw then encoded in place   [blk*6+ch]
+    int16_t mask[36][50];
+    uint8_t bapb[6][256];       // bap of the block being packed
+    uint32_t fr[PK_FRW];        // frame as MSB-first dwords
+    uint16_t gcode[3][576];
+    uint16_t goff[3][576];
+    int diff[6][6];
+    uint8_t strat[6][6];
+    uint8_t latab[256];
+    uint16_t hth[50];
+    uint8_t baptab[64];
+    uint8_t band_of_bin[256];
+    uint8_t band_start[52];
+    uint8_t band_size[52];
+    uint16_t crc_tab[256];
+};
+
+__device__ __forceinline__ void put_bits(uint32_t *fr, uint32_t pos, int n, uint32_t v)
+{
+    if (n <= 0) return;
+    const uint32_t w = pos >> 5;
+    if (w + 1 >= (uint32_t)PK_FRW) return;
+    const uint64_t x = (uint64_t)v << (64 - n - (pos & 31));
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (hi) atomicOr(&fr[w], hi);
+    if (lo) atomicOr(&fr[w + 1], lo);
+}
+
+__device__ __forceinline__ int lowcomp_step(int a, int b0, int b1, int bin)     // :183-215
+{
+    if (bin < 7) {
+        if (b0 + 256 == b1) a = 384;
+        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
+    } else if (bin < 20) {
+        if (b0 + 256 == b1) a = 320;
+        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
+    } else {
+        a -= 128; if (a < 0) a = 0;
+    }
+    return a;
+}
+
+// PSD integration, excitation and mask for one (block, channel) - run by ONE lane.  :220-367
+__device__ void compute_mask_lane(PackLDS &L, const uint8_t *exp, int end, bool is_lfe, int16_t *mask,
+                                  int sdecay, int fdecay, int sgain, int dbknee, int fgain, int halfrate)
+{
+    int16_t bndpsd[50], excite[50];
+    int j = 0, k = 0, v, lowcomp = 0, fast = 0, slow = 0, begin, end1, bin;
+    do {
+        v = 3072 - ((int)(int8_t)exp[j] << 7);
+        j++;
+        end1 = L.band_start[k + 1] < end ? L.band_start[k + 1] : end;
+        for (; j < end1; j++) {
+            const int pj = 3072 - ((int)(int8_t)exp[j] << 7);
+            const int c = v - pj;
+            int a;
+            if (c >= 0) { a = c >> 1; if (a > 255) a = 255; v = v + L.latab[a]; }
+            else { a = (-c) >> 1; if (a > 255) a = 255; v = pj + L.latab[a]; }
+        }
+        bndpsd[k++] = (int16_t)v;
+    } while (end > L.band_start[k]);
+
+    const int bndend = L.band_of_bin[end - 1] + 1;
+    lowcomp = lowcomp_step(lowcomp, bndpsd[0], bndpsd[1], 0);
+    excite[0] = (int16_t)(bndpsd[0] - fgain - lowcomp);
+    lowcomp = lowcomp_step(lowcomp, bndpsd[1], bndpsd[2], 1);
+    excite[1] = (int16_t)(bndpsd[1] - fgain - lowcomp);
+    begin = 7;
+    for (bin = 2; bin < 7; bin++) {
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
+        fast = bndpsd[bin] - fgain;
+        slow = bndpsd[bin] - sgain;
+        excite[bin] = (int16_t)(fast - lowcomp);
+        if (!(is_lfe && bin == 6) && bndpsd[bin] <= bndpsd[bin + 1]) { begin = bin + 1; break; }
+    }
+    end1 = bndend > 22 ? 22 : bndend;
+    for (bin = begin; bin < end1; bin++) {
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
+        fast -= fdecay; v = bndpsd[bin] - fgain; if (fast < v) fast = v;
+        slow -= sdecay; v = bndpsd[bin] - sgain; if (slow < v) slow = v;
+        v = fast - lowcomp; if (slow > v) v = slow;
+        excite[bin] = (int16_t)v;
+    }
+    for (bin = 22; bin < bndend; bin++) {
+        fast -= fdecay; v = bndpsd[bin] - fgain; if (fast < v) fast = v;
+        slow -= sdecay; v = bndpsd[bin] - sgain; if (slow < v) slow = v;
+        excite[bin] = (int16_t)(fast > slow ? fast : slow);
+    }
+    for (bin = 0; bin < bndend; bin++) {
+        int v1 = excite[bin];
+        const int t = dbknee - bndpsd[bin];
+        if (t > 0) v1 += t >> 2;
+        v = L.hth[bin >> halfrate];
+        mask[bin] = (int16_t)(v1 > v ? v1 : v);
+    }
+    for (bin = bndend; bin < 50; bin++) mask[bin] = 0;
+}
+
+// constrain_exponents = encode_exp (:684-761), in place on one 256-byte row, run by ONE lane.
+// (nb_groups counts exponent entries after grouping: up to 222 for D15.)
+__device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
+{
+    const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
+    const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
+    // group minima, compacted to row[1..ng] (reads run ahead of writes: k >= i)
+    for (int i = 1, k = 1; i <= ng; i++, k += gs) {
+        int m = row[k];
+        for (int j = 1; j < gs; j++) if (row[k + j] < m) m = row[k + j];
+        row[i] = (uint8_t)m;
+    }
+    if (row[0] > 15) row[0] = 15;
+    // fixed point of the +-2 delta constraint = min_j g[j] + 2|i-j|: forward then backward sweep
+    for (int i = 1; i <= ng; i++) if (row[i] > row[i - 1] + 2) row[i] = (uint8_t)(row[i - 1] + 2);
+    for (int i = ng - 1; i >= 0; i--) if (row[i] > row[i + 1] + 2) row[i] = (uint8_t)(row[i + 1] + 2);
+    // expand back to bins, last group first (writes stay at or above the group index)
+    for (int i = ng, k = 1 + (ng - 1) * gs; i >= 1; i--, k -= gs) {
+        const uint8_t v = row[i];
+        for (int j = gs - 1; j >= 0; j--) row[k + j] = v;
+    }
+    return 4 + (ng / 3) * 7;
+}
+
+__device__ __forceinline__ int bap_of(const PackLDS &L, int m, int e, int snroffset, int floorv)
+{
+    int v = m - snroffset - floorv;
+    if (v < 0) v = 0;
+    v = (v & 0x1fe0) + floorv;
+    int a = ((3072 - ((int)(int8_t)e << 7)) - v) >> 5;
+    a = a < 0 ? 0 : a > 63 ? 63 : a;
+    return L.baptab[a];
+}
+
+// mantissa bits of the whole frame for one SNR offset (:764-845): wave-wide count
+__device__ int mantissa_bits(const PackLDS &L, const PackParams &P, int snroffset, int floorv, int lane)
+{
+    const int T = P.nfbw * P.nbc + (P.lfe ? 7 : 0);
+    int total = 0;
+    for (int b = 0; b < 6; b++) {
+        int cnt = 0, bits = 0;
+        for (int t = lane; t < T; t += 64) {
+            int ch = t / P.nbc, bin = t - ch * P.nbc;
+            if (ch >= P.nfbw) { ch = P.nfbw; bin = t - P.nfbw * P.nbc; }
+            const int r = b * 6 + ch;
+            const int bp = bap_of(L, L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset, floorv);
+            if (bp == 1) cnt += 1;
+            else if (bp == 2) cnt += 1 << 11;
+            else if (bp == 4) cnt += 1 << 22;
+            else if (bp == 3) bits += 3;
+            else if (bp == 14) bits += 14;
+            else if (bp == 15) bits += 16;
+            else if (bp) bits += bp - 1;
+        }
+        cnt = wave_sum(cnt);
+        bits = wave_sum(bits);
+        const int n1 = cnt & 0x7ff, n2 = (cnt >> 11) & 0x7ff, n4 = (cnt >> 22) & 0x3ff;
+        total += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+    }
+    return total;
+}
+
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :1513-1524, poly 0x18005
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (a & 1) c ^= b;
+        a >>= 1;
+        b <<= 1;
+        if (b & 0x10000u) b ^= 0x18005u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ int quant_sym(int c, int e, int levels)       // :1150-1166
+{
+    int v;
+    e &= 31;
+    if (c >= 0) { v = (levels * (c << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) + v; }
+    else { v = (levels * ((-c) << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) - v; }
+    return v;
+}
+__device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :1169-1190
+{
+    const int lshift = e + qbits - 24;
+    int v;
+    if (lshift >= 0) v = (int)((unsigned)c << (lshift & 31));
+    else v = c >> ((-lshift) & 31);
+    v = (v + 1) >> 1;
+    const int m = 1 << (qbits - 1);
+    if (v >= m) v = m - 1;
+    return v & ((1 << qbits) - 1);
+}
+
+// CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
+// bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
+__device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
+{
+    const int start = end - 64 * C;                 // may be negative: leading zero padding
+    int p = start + lane * C;
+    uint32_t crc = 0;
+    for (int i = 0; i < C; i++, p++) {
+        uint32_t byte = 0;
+        if (p >= end - len && p >= zero_below) byte = (L.fr[p >> 2] >> (24 - 8 * (p & 3))) & 0xff;
+        crc = (L.crc_tab[byte ^ (crc >> 8)] ^ (crc << 8)) & 0xffff;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int d = 1 << k;
+        const uint32_t left = __shfl_up(crc, d, 64);
+        if (((lane + 1) & (2 * d - 1)) == 0) crc = gf_mul(left, pw[k]) ^ crc;
+    }
+    return __shfl(crc, 63, 64);
+}
+
+__global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
+{
+    __shared__ PackLDS L;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    if (s >= P.n_streams) return;
+
+    for (int i = lane; i < 256; i += 64) {
+        L.latab[i] = P.tab->latab[i];
+        L.band_of_bin[i] = P.tab->band_of_bin[i];
+        L.crc_tab[i] = P.tab->crc_tab[i];
+    }
+    if (lane < 50) L.hth[lane] = P.tab->hth[lane][P.fscod];
+    L.baptab[lane] = P.tab->baptab[lane];
+    if (lane < 52) { L.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0; L.band_size[lane] = lane < 50 ? P.tab->band_size[lane] : 0; }
+
+    // fixed allocation codes (:861-879)
+    const int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
+    const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
+    const int sgain = 0x4d8, dbknee = 0x900, floorv = 0x1f0, fgain = 128 * (fgaincod + 1);
+    const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
+    const int T = nfbw * nbc + (P.lfe ? 7 : 0);
+    const int fs = P.frame_words;
+
+    int csnr_prev = P.csnr_state[s];
+
+    for (int f = 0; f < P.frames_per_stream; f++) {
+        const size_t fidx = (size_t)s * P.frames_per_stream + f;
+        const uint8_t *ex = P.expo + fidx * 6 * nch * 256;
+        const int32_t *md = P.mdct + fidx * 6 * nch * 256;
+        const int8_t *sh = P.shift + fidx * 6 * nch;
+
+        // ---- raw exponents into LDS ----
+        for (int r = 0; r < 36; r++) {
+            const int b = r / 6, ch = r - 6 * b;
+            uint32_t v = 0x18181818u;
+            if (ch < nch) v = *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane);
+            *reinterpret_cast<uint32_t *>(&L.E[r][4 * lane]) = v;
+        }
+        for (int i = lane; i < PK_FRW; i += 64) L.fr[i] = 0;
+        WAVE_SYNC();
+
+        // ---- exponent strategy (:617-669) ----
+        for (int ch = 0; ch < nch; ch++)
+            for (int b = 1; b < 6; b++) {
+                int d = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = lane + 64 * k;
+                    const int x = (int)L.E[b * 6 + ch][j] - (int)L.E[(b - 1) * 6 + ch][j];
+                    d += x < 0 ? -x : x;
+                }
+                d = wave_sum(d);
+                if (lane == 0) L.diff[ch][b] = d;
+            }
+        WAVE_SYNC();
+        if (lane < nch) {
+            const int ch = lane;
+            uint8_t st[6];
+            st[0] = 1;
+            for (int b = 1; b < 6; b++) st[b] = L.diff[ch][b] > 1000 ? 1 : 0;
+            if (!(P.lfe && ch == nch - 1)) {
+                for (int b = 0; b < 6;) {
+                    int e = b + 1;
+                    while (e < 6 && st[e] == 0) e++;
+                    st[b] = (e - b == 1) ? 3 : (e - b <= 3) ? 2 : 1;
+                    b = e;
+                }
+            }
+            for (int b = 0; b < 6; b++) L.strat[b][ch] = st[b];
+        }
+        WAVE_SYNC();
+
+        // ---- min-merge over reuse runs (:1731-1737), lanes over bins ----
+        for (int ch = 0; ch < nch; ch++) {
+            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+            int b = 0;
+            while (b < 6) {
+                int e = b + 1;
+                while (e < 6 && L.strat[e][ch] == 0) {
+                    for (int j = lane; j < n; j += 64) {
+                        const uint8_t x = L.E[e * 6 + ch][j];
+                        if (x < L.E[b * 6 + ch][j]) L.E[b * 6 + ch][j] = x;
+                    }
+                    e++;
+                }
+                b = e;
+            }
+        }
+        WAVE_SYNC();
+
+        // ---- encode_exp on run starts (one lane per (blk, ch)), then replicate (:1739-1746) ----
+        int exp_bits = 0;
+        if (lane < 36) {
+            const int b = lane / 6, ch = lane - 6 * b;
+            if (ch < nch && L.strat[b][ch] != 0) {
+                const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                exp_bits = encode_exp_lane(L.E[lane], n, L.strat[b][ch]);
+            }
+        }
+        int frame_bits = wave_sum(exp_bits);
+        WAVE_SYNC();
+        for (int ch = 0; ch < nch; ch++) {
+            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+            int src = 0;
+            for (int b = 1; b < 6; b++) {
+                if (L.strat[b][ch] != 0) { src = b; continue; }
+                for (int j = lane; j < n; j += 64) L.E[b * 6 + ch][j] = L.E[src * 6 + ch][j];
+            }
+        }
+        WAVE_SYNC();
+
+        // ---- masks: one lane per (blk, ch) ----
+        if (lane < 36) {
+            const int b = lane / 6, ch = lane - 6 * b;
+            if (ch < nch) {
+                const bool is_lfe = P.lfe && ch == nch - 1;
+                compute_mask_lane(L, L.E[lane], is_lfe ? 7 : nbc, is_lfe, L.mask[lane], sdecay, fdecay, sgain, dbknee,
+                                  fgain, P.halfrate);
+            }
+        }
+        WAVE_SYNC();
+
+        // ---- fixed side information (:880-916) ----
+        {
+            const int extra[8] = {0, 0, 2, 2, 2, 4, 2, 4};
+            frame_bits += 65 + extra[P.acmod & 7];
+            for (int b = 0; b < 6; b++) {
+                frame_bits += nfbw * 2 + 2;
+                if (P.acmod == 2) frame_bits++;
+                frame_bits += 2 * nfbw;
+                if (P.lfe) frame_bits++;
+                for (int ch = 0; ch < nfbw; ch++)
+                    if (L.strat[b][ch] != 0) frame_bits += 6 + 2;
+                frame_bits += 1 + 1 + 2;
+            }
+            frame_bits++;
+            frame_bits += 2 * 4 + 3 + 6 + nch * (4 + 3);
+            frame_bits += 2;
+            frame_bits += 16;
+        }
+
+        // ---- SNR offset search, exactly the reference's sequence (:921-967) ----
+        const int budget = 16 * fs - frame_bits;
+        auto fits = [&](int c, int fsn) -> bool {
+            const int so = (((c - 15) << 4) + fsn) << 2;
+            return budget - mantissa_bits(L, P, so, floorv, lane) >= 0;
+        };
+        int csnr = csnr_prev, fsnr = 0;
+        bool failed = false;
+        while (csnr >= 0 && !fits(csnr, 0)) csnr -= 4;
+        if (csnr < 0) failed = true;
+        if (!failed) {
+            while (csnr + 4 <= 63 && fits(csnr + 4, 0)) csnr += 4;
+            while (csnr + 1 <= 63 && fits(csnr + 1, 0)) csnr++;
+            while (fsnr + 4 <= 15 && fits(csnr, fsnr + 4)) fsnr += 4;
+            while (fsnr + 1 <= 15 && fits(csnr, fsnr + 1)) fsnr++;
+            csnr_prev = csnr;
+        } else {
+            // reference: error path keeps the stored offsets and emits the last tried allocation;
+            // out of contract for any supported bit rate - emit offset 0
+            csnr = 0;
+            fsnr = 0;
+        }
+        const int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
+        if (P.tap_snr && lane == 0) { P.tap_snr[fidx * 2] = csnr; P.tap_snr[fidx * 2 + 1] = fsnr; }
+        if (P.tap_strat && lane < 36) {
+            const int b = lane / 6, ch = lane - 6 * b;
+            if (ch < nch) P.tap_strat[(fidx * 6 + b) * nch + ch] = L.strat[b][ch];
+        }
+
+        // ---- header (:1113-1147) ----
+        uint32_t pos = 0;
+        auto put = [&](int n, uint32_t v) {
+            if (lane == 0) put_bits(L.fr, pos, n, v);
+            pos += n;
+        };
+        put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+        if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
+        if (P.acmod & 4) put(2, 1);
+        if (P.acmod == 2) put(2, 0);
+        put(1, P.lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
+
+        // ---- audio blocks (:1194-1502) ----
+        for (int b = 0; b < 6; b++) {
+            for (int ch = 0; ch < nfbw; ch++) put(1, 0);
+            for (int ch = 0; ch < nfbw; ch++) put(1, 1);
+            put(1, 0);
+            if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
+            if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
+            for (int ch = 0; ch < nfbw; ch++) put(2, L.strat[b][ch]);
+            if (P.lfe) put(1, L.strat[b][nch - 1]);
+            for (int ch = 0; ch < nfbw; ch++) if (L.strat[b][ch] != 0) put(6, P.chbwcod);
+            // exponents: lanes over groups
+            for (int ch = 0; ch < nch; ch++) {
+                const int stg = L.strat[b][ch];
+                if (stg == 0) continue;
+                const bool is_lfe = P.lfe && ch == nch - 1;
+                const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
+                const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
+                const uint8_t *e = L.E[b * 6 + ch];
+                put(4, e[0]);
+                for (int g = lane; g < ng; g += 64) {
+                    const int k0 = 1 + 3 * g * gs;
+                    const int prev = g ? e[k0 - gs] : e[0];
+                    const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
+                    put_bits(L.fr, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+                }
+                pos += 7 * ng;
+                if (!is_lfe) put(2, 0);
+            }
+            put(1, b == 0);
+            if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
+            put(1, b == 0);
+            if (b == 0) {
+                put(6, csnr);
+                for (int ch = 0; ch < nch; ch++) { put(4, fsnr); put(3, fgaincod); }
+            }
+            put(1, 0);
+            put(1, 0);
+
+            // ---- mantissas ----
+            // pass 1: bap of every coefficient of this block, group ranks
+            const int R = (T + 63) >> 6;
+            const int t0 = lane * R < T ? lane * R : T, t1 = (lane + 1) * R < T ? (lane + 1) * R : T;
+            int n3 = 0, n5 = 0, n11 = 0;
+            for (int t = t0; t < t1; t++) {
+                int ch = t / nbc, bin = t - ch * nbc;
+                if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
+                const int r = b * 6 + ch;
+                const int bp = bap_of(L, L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset, floorv);
+                L.bapb[ch][bin] = (uint8_t)bp;
+                n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
+            }
+            for (int i = lane; i < 576; i += 64) { L.gcode[0][i] = 0; L.gcode[1][i] = 0; L.gcode[2][i] = 0; }
+            int tot3, tot5, tot11, totbits;
+            const int r3 = wave_excl_scan(n3, lane, &tot3), r5 = wave_excl_scan(n5, lane, &tot5);
+            const int r11 = wave_excl_scan(n11, lane, &tot11);
+            // pass 2: widths
+            int nbits = 0;
+            {
+                int c3 = r3, c5 = r5, c11 = r11;
+                for (int t = t0; t < t1; t++) {
+                    int ch = t / nbc, bin = t - ch * nbc;
+                    if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
+                    const int bp = L.bapb[ch][bin];
+                    if (bp == 1) { if (c3 % 3 == 0) nbits += 5; c3++; }
+                    else if (bp == 2) { if (c5 % 3 == 0) nbits += 7; c5++; }
+                    else if (bp == 4) { if ((c11 & 1) == 0) nbits += 7; c11++; }
+                    else if (bp == 3) nbits += 3;
+                    else if (bp == 14) nbits += 14;
+                    else if (bp == 15) nbits += 16;
+                    else if (bp) nbits += bp - 1;
+                }
+            }
+            uint32_t off = pos + (uint32_t)wave_excl_scan(nbits, lane, &totbits);
+            WAVE_SYNC();
+            // pass 3: quantise; plain mantissas go straight into the frame
+            {
+                int c3 = r3, c5 = r5, c11 = r11;
+                for (int t = t0; t < t1; t++) {
+                    int ch = t / nbc, bin = t - ch * nbc;
+                    if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
+                    const int bp = L.bapb[ch][bin];
+                    if (!bp) continue;
+                    const int c = md[((size_t)b * nch + ch) * 256 + bin];
+                    const int e = (int)L.E[b * 6 + ch][bin] - (int)sh[b * nch + ch];
+                    if (bp == 1) {
+                        const int v = quant_sym(c, e, 3), m = c3 % 3, g = c3 / 3;
+                        if (m == 0) { L.goff[0][g] = (uint16_t)(off - pos); off += 5; }
+                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[0][g & ~1]), (unsigned)(v * (m == 0 ? 9 : m == 1 ? 3 : 1)) << (16 * (g & 1)));
+                        c3++;
+                    } else if (bp == 2) {
+                        const int v = quant_sym(c, e, 5), m = c5 % 3, g = c5 / 3;
+                        if (m == 0) { L.goff[1][g] = (uint16_t)(off - pos); off += 7; }
+                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[1][g & ~1]), (unsigned)(v * (m == 0 ? 25 : m == 1 ? 5 : 1)) << (16 * (g & 1)));
+                        c5++;
+                    } else if (bp == 4) {
+                        const int v = quant_sym(c, e, 11), m = c11 & 1, g = c11 >> 1;
+                        if (m == 0) { L.goff[2][g] = (uint16_t)(off - pos); off += 7; }
+                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[2][g & ~1]), (unsigned)(v * (m == 0 ? 11 : 1)) << (16 * (g & 1)));
+                        c11++;
+                    } else {
+                        int v, w;
+                        if (bp == 3) { v = quant_sym(c, e, 7); w = 3; }
+                        else if (bp == 5) { v = quant_sym(c, e, 15); w = 4; }
+                        else if (bp == 14) { v = quant_asym(c, e, 14); w = 14; }
+                        else if (bp == 15) { v = quant_asym(c, e, 16); w = 16; }
+                        else { v = quant_asym(c, e, bp - 1); w = bp - 1; }
+                        put_bits(L.fr, off, w, (uint32_t)v);
+                        off += w;
+                    }
+                }
+            }
+            WAVE_SYNC();
+            // pass 4: grouped codes
+            for (int g = lane; g < (tot3 + 2) / 3; g += 64) put_bits(L.fr, pos + L.goff[0][g], 5, L.gcode[0][g]);
+            for (int g = lane; g < (tot5 + 2) / 3; g += 64) put_bits(L.fr, pos + L.goff[1][g], 7, L.gcode[1][g]);
+            for (int g = lane; g < (tot11 + 1) / 2; g += 64) put_bits(L.fr, pos + L.goff[2][g], 7, L.gcode[2][g]);
+            pos += (uint32_t)totbits;
+            if (P.tap_bap) {
+                uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
+                uint8_t *te = P.tap_eexp + (fidx * 6 + b) * nch * 256;
+                for (int ch = 0; ch < nch; ch++)
+                    for (int i = lane; i < 256; i += 64) {
+                        const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                        tb[ch * 256 + i] = i < n ? L.bapb[ch][i] : 0;
+                        te[ch * 256 + i] = L.E[b * 6 + ch][i];
+                    }
+            }
+            WAVE_SYNC();
+        }
+
+        // ---- frame end (:1599-1638): bytes past 2*fs are dropped, CRCs stored over whatever is there ----
+        const int fs58 = (fs >> 1) + (fs >> 3);
+        // clear everything from byte 2*fs-2 on? no: the reference only zero-pads when the data is short;
+        // data bits beyond byte 2*fs-2 stay and are then overwritten by crc2 (its own overshoot quirk)
+        uint32_t crc1 = region_crc(L, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
+        crc1 = gf_mul(P.crc_inv, crc1);
+        const uint32_t crc2 = region_crc(L, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
+        WAVE_SYNC();
+        if (lane == 0) {
+            L.fr[0] = (L.fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
+            const int p = 2 * fs - 2;                                                 // even -> inside one dword
+            const int shft = 16 - 8 * (p & 3);
+            L.fr[p >> 2] = (L.fr[p >> 2] & ~(0xffffu << shft)) | ((crc2 & 0xffff) << shft);
+        }
+        WAVE_SYNC();
+        uint8_t *dst = P.frames + fidx * P.frame_stride;
+        for (int i = lane; i < (2 * fs + 3) / 4; i += 64) {
+            uint32_t v = __builtin_bswap32(L.fr[i]);
+            const int rem = 2 * fs - 4 * i;
+            if (rem >= 4) *reinterpret_cast<uint32_t *>(dst + 4 * i) = v;
+            else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
+        }
+        WAVE_SYNC();
+    }
+    if (lane == 0) P.csnr_state[s] = csnr_prev;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+static uint32_t h_gf_mul(uint32_t a, uint32_t b)
+{
+    uint32_t c = 0;
+    while (a) {
+        if (a & 1) c ^= b;
+        a >>= 1;
+        b <<= 1;
+        if (b & 0x10000u) b ^= 0x18005u;
+    }
+    return c;
+}
+static uint32_t h_gf_pow(uint32_t a, uint32_t n)
+{
+    uint32_t r = 1;
+    while (n) {
+        if (n & 1) r = h_gf_mul(r, a);
+        a = h_gf_mul(a, a);
+        n >>= 1;
+    }
+    return r;
+}
+
+hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStream_t stream)
+{
+    if (E.n_streams <= 0 || E.frames_per_stream <= 0) return hipSuccess;
+    const EncConfig &c = E.cfg;
+    MdctParams M;
+    M.pcm = E.pcm;
+    M.last = E.last;
+    M.mdct = E.ws_mdct;
+    M.expo = E.ws_expo;
+    M.shift = E.ws_shift;
+    M.tab = tab.enc;
+    M.n_streams = E.n_streams;
+    M.frames = E.frames_per_stream;
+    M.nch = c.nch;
+    for (int i = 0; i < 8; i++) M.chmap[i] = E.chmap[i];
+    hipLaunchKernelGGL(enc_mdct_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, M);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    PackParams P;
+    P.mdct = E.ws_mdct;
+    P.expo = E.ws_expo;
+    P.shift = E.ws_shift;
+    P.csnr_state = E.csnr;
+    P.frames = E.frames;
+    P.tab = tab.enc;
+    P.tap_eexp = E.tap_eexp;
+    P.tap_bap = E.tap_bap;
+    P.tap_strat = E.tap_strat;
+    P.tap_snr = E.tap_snr;
+    P.n_streams = E.n_streams;
+    P.frames_per_stream = E.frames_per_stream;
+    P.frame_stride = E.frame_stride;
+    P.nch = c.nch;
+    P.nfbw = c.nfbw;
+    P.lfe = c.lfe;
+    P.acmod = c.acmod;
+    P.fscod = c.fscod;
+    P.halfrate = c.halfrate;
+    P.bsid = c.bsid;
+    P.frmsizecod = c.frmsizecod;
+    P.frame_words = c.frame_words;
+    P.nbc = 223;
+    P.chbwcod = 50;
+    const int fs = c.frame_words, fs58 = (fs >> 1) + (fs >> 3);
+    P.crc_inv = h_gf_pow(0x18005 >> 1, 16 * fs58 - 16);
+    const int len1 = 2 * fs58, len2 = (fs - fs58) * 2 - 2;
+    P.c1 = (len1 + 63) / 64;
+    P.c2 = (len2 + 63) / 64;
+    for (int k = 0; k < 6; k++) {
+        P.pw1[k] = h_gf_pow(2, 8u * P.c1 * (1u << k));
+        P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
+    }
+    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), 0, stream, P);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the new history: last 256 samples per channel of each stream's final frame
+    return launch_enc_history(E, stream);
+}
+
+__global__ void enc_history_kernel(const int16_t *pcm, int16_t *last, int n_streams, int frames, int nch, const uint8_t c0,
+                                   const uint8_t c1, const uint8_t c2, const uint8_t c3, const uint8_t c4, const uint8_t c5)
+{
+    const uint8_t chmap[6] = {c0, c1, c2, c3, c4, c5};
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // (s*nch + ch)*256 + j
+    if (idx >= n_streams * nch * 256) return;
+    const int j = idx & 255, ch = (idx >> 8) % nch, s = (idx >> 8) / nch;
+    const int16_t *fp = pcm + ((size_t)s * frames + (frames - 1)) * 1536 * nch;
+    last[idx] = fp[(size_t)(5 * 256 + j) * nch + chmap[ch]];
+}
+
+hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream)
+{
+    const int n = E.n_streams * E.cfg.nch * 256;
+    hipLaunchKernelGGL(enc_history_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, E.pcm, E.last, E.n_streams,
+                       E.frames_per_stream, E.cfg.nch, E.chmap[0], E.chmap[1], E.chmap[2], E.chmap[3], E.chmap[4], E.chmap[5]);
+    return hipGetLastError();
+}
+
+}  // namespace ac3mi

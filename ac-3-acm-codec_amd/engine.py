@@ -37,6 +37,21 @@ class DecodeDesc:
                                 self.frame_bytes)
 
 
+@dataclass
+class EncodeDesc:
+    """AC3_encode_init's arguments (src/ac3enc/ac3enc.h:6)."""
+    sample_rate: int = 48000
+    bit_rate: int = 384000
+    channels: int = 6
+
+    def c(self):
+        return capi.EncodeDescC(self.sample_rate, self.bit_rate, self.channels)
+
+    def frame_bytes(self):
+        c = self.c()
+        return capi.load_library().ac3mi_encode_frame_bytes(ctypes.byref(c))
+
+
 def syncinfo(buf):
     """a52_syncinfo on host bytes -> (frame_bytes, flags, sample_rate, bit_rate); frame_bytes 0 = no frame."""
     lib = capi.load_library()
@@ -162,3 +177,44 @@ class Engine:
         if taps:
             return out, status, tdict
         return out, status
+
+    def encode_batch(self, desc, pcm, chmap, last, csnroffst, out=None, taps=False, wait_torch=True):
+        """pcm [S][F][1536][nch] s16, chmap = nch ints, last [S][nch][256] s16, csnroffst [S] i32 (both
+        updated in place) -> frames [S][F][stride] u8 (stride = frame bytes rounded up to 4)[, taps dict]."""
+        import torch
+        if wait_torch:
+            torch.cuda.synchronize(self.device)
+        fb = desc.frame_bytes()
+        if fb <= 0:
+            raise capi.AC3MIError("AC3_encode_init would reject %r" % (desc,))
+        S, F, n, nch = pcm.shape
+        assert n == 1536 and nch == desc.channels and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.is_cuda
+        assert last.dtype == torch.int16 and tuple(last.shape) == (S, nch, 256) and last.is_contiguous()
+        assert csnroffst.dtype == torch.int32 and tuple(csnroffst.shape) == (S,)
+        stride = (fb + 3) & ~3
+        dev = pcm.device
+        if out is None:
+            out = torch.zeros((S, F, stride), dtype=torch.uint8, device=dev)
+        cm = (ctypes.c_uint8 * 8)(*(list(chmap) + [0] * 8)[:8])
+        tp, tdict = None, None
+        if taps:
+            tdict = {
+                "mdct": torch.zeros((S, F, 6, nch, 256), dtype=torch.int32, device=dev),
+                "exponent": torch.zeros((S, F, 6, nch, 256), dtype=torch.uint8, device=dev),
+                "exp_samples": torch.zeros((S, F, 6, nch), dtype=torch.int8, device=dev),
+                "encoded_exp": torch.zeros((S, F, 6, nch, 256), dtype=torch.uint8, device=dev),
+                "bap": torch.zeros((S, F, 6, nch, 256), dtype=torch.uint8, device=dev),
+                "exp_strategy": torch.zeros((S, F, 6, nch), dtype=torch.uint8, device=dev),
+                "snroffst": torch.zeros((S, F, 2), dtype=torch.int32, device=dev),
+            }
+            torch.cuda.synchronize(self.device)
+            tp = capi.EncodeTapsC(*(tdict[k].data_ptr() for k in ("mdct", "exponent", "exp_samples", "encoded_exp",
+                                                                   "bap", "exp_strategy", "snroffst")))
+        c = desc.c()
+        self._check(self.lib.ac3mi_encode_batch(self.ctx, ctypes.byref(c), pcm.data_ptr(), cm, last.data_ptr(),
+                                                csnroffst.data_ptr(), out.data_ptr(), stride, S, F,
+                                                ctypes.byref(tp) if tp else None))
+        self._keep.append((pcm, last, csnroffst, out, tdict))
+        if taps:
+            return out, tdict
+        return out

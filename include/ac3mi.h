@@ -171,6 +171,48 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
                        uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status,
                        const ac3mi_decode_taps *taps);
 
+/* ---- frame encode: PCM -> bitstream ------------------------------------------- */
+
+/* Replaces, for a batch of independent streams, AC3_encode_init + AC3_encode_frame
+ * (ENC/ac3enc.h:6-7; ENC/ac3enc.cpp:1019-1110, 1640-1763) as driven by stream_convert_pcm
+ * (src/AC3ACM.cpp:1762).  The descriptor holds AC3_encode_init's three arguments. */
+typedef struct {
+    int sample_rate;    /* 48000/44100/32000 and their halves and quarters */
+    int bit_rate;       /* bits per second, one of the 19 AC-3 rates (shifted for half rates) */
+    int channels;       /* 1..6; 6 = 3/2 + LFE */
+} ac3mi_encode_desc;
+
+/* optional per-stage outputs for parity tests; any pointer may be NULL
+ * (d_bap and d_encoded_exp only together) */
+typedef struct {
+    int32_t *d_mdct;            /* [S][F][6][nch][256]  mdct_coef   (ENC/ac3enc.cpp:82)  */
+    uint8_t *d_exponent;        /* [S][F][6][nch][256]  exponent    (:83), before min-merge */
+    int8_t *d_exp_samples;      /* [S][F][6][nch]       exp_samples (:87) */
+    uint8_t *d_encoded_exp;     /* [S][F][6][nch][256]  encoded_exp (:85) */
+    uint8_t *d_bap;             /* [S][F][6][nch][256]  bap         (:86) */
+    uint8_t *d_exp_strategy;    /* [S][F][6][nch]       exp_strategy (:84) */
+    int32_t *d_snroffst;        /* [S][F][2]            csnroffst, fsnroffst chosen for the frame */
+} ac3mi_encode_taps;
+
+/* AC3_encode_init's return value: frame size in bytes, 0 for an unsupported combination */
+int ac3mi_encode_frame_bytes(const ac3mi_encode_desc *desc);
+
+/* the Q15 tables AC3_encode_init builds on the host (fft_init, xcos1/xsin1) and the window */
+int ac3mi_encode_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128, int16_t *window256);
+
+/* d_pcm        [n_streams][frames_per_stream][1536][channels] s16 interleaved (AC3_encode_frame's `samples`)
+ * chmap        HOST array, `channels` entries: input slot of coded channel ch (AC3_encode_frame's `chmap`;
+ *              the driver passes {0,2,1,4,5,3} for 6-channel WAVE order, src/AC3ACM.cpp:1631-1662)
+ * d_last       [n_streams][channels][256] s16: last_samples (ENC/ac3enc.cpp:55), read and rewritten
+ * d_csnroffst  [n_streams] int32: coarse SNR offset the search starts from (AC3_encode_init sets 40,
+ *              :1092; each frame stores its result, :969), read and rewritten
+ * d_frames     [n_streams][frames_per_stream] frames, frame_stride bytes apart (multiple of 4)
+ */
+int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int16_t *d_pcm,
+                       const uint8_t *chmap, int16_t *d_last, int32_t *d_csnroffst, uint8_t *d_frames,
+                       int frame_stride, int n_streams, int frames_per_stream,
+                       const ac3mi_encode_taps *taps);
+
 #ifdef __cplusplus
 }
 #endif
