@@ -49,9 +49,12 @@ def declared_symbols():
             continue
         text = open(os.path.join(HEADER_DIR, fn)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"typedef[^;{]*\(\s*\*[^;]*;", "", text)        # function-pointer typedefs
         for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text):
-            if m.group(1) not in ("defined", "sizeof"):
+            if m.group(1) not in ("defined", "sizeof", "void", "int"):
                 names.append(m.group(1))
+        for m in re.finditer(r"extern\s+\w+\s+(\w+)\s*\[", text):      # exported tables (MapTab)
+            names.append(m.group(1))
     return sorted(set(names))
 
 

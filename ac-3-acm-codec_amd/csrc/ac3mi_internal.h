@@ -103,6 +103,9 @@ hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream);
 void build_enc_tables(EncTables *t);
 int enc_config(int freq, int bitrate, int channels, EncConfig *c);   // 0 = rejected (AC3_encode_init returns 0)
 
+hipError_t launch_convert_s16(const float *planes, int16_t *out, int flags, size_t n_blocks, hipStream_t stream);
+int s16_channel_map(int flags, int map[6]);
+
 void build_host_tables(float *window256, float2 *tw_long /*[8][16]*/, float2 *tw_short /*[8][16]*/);
 
 }  // namespace ac3mi

@@ -547,8 +547,6 @@ static int ensure_ws(ac3mi_ctx *ctx, size_t coef_bytes, size_t blksw_bytes)
     if (blksw_bytes > ctx->ws_blksw_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_blksw);
-    (void)hipFree(ctx->ws_enc);
-    (void)hipFree(ctx->tab.enc);
         ctx->ws_blksw = nullptr;
         ctx->ws_blksw_bytes = 0;
         HIPCHK(ctx, hipMalloc(&ctx->ws_blksw, blksw_bytes));

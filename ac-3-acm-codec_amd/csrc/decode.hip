@@ -46,7 +46,7 @@ struct DecLDS {
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
     float plane[6][256];                  // 0..4 fbw, 5 = lfe
-    uint16_t goff[3][512];                // bit offset of the first member of each 3/5/11-level group
+    uint16_t goff[3][768];                // bit offset of the first member of each 3/5/11-level group (<= 744)
     uint8_t cplbnd[20];                   // coupling sub-band -> band
     int16_t seg_base[9];                  // mantissa stream segments
     uint8_t seg_ch[8], seg_start[8];

@@ -243,8 +243,8 @@ struct PackLDS {
     int16_t mask[36][50];
     uint8_t bapb[6][256];       // bap of the block being packed
     uint32_t fr[PK_FRW];        // frame as MSB-first dwords
-    uint16_t gcode[3][576];
-    uint16_t goff[3][576];
+    uint16_t gcode[3][768];             // up to 1500/2 groups of the 11-level kind
+    uint16_t goff[3][768];
     int diff[6][6];
     uint8_t strat[6][6];
     uint8_t latab[256];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
                 L.bapb[ch][bin] = (uint8_t)bp;
                 n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
             }
-            for (int i = lane; i < 576; i += 64) { L.gcode[0][i] = 0; L.gcode[1][i] = 0; L.gcode[2][i] = 0; }
+            for (int i = lane; i < 768; i += 64) { L.gcode[0][i] = 0; L.gcode[1][i] = 0; L.gcode[2][i] = 0; }
             int tot3, tot5, tot11, totbits;
             const int r3 = wave_excl_scan(n3, lane, &tot3), r5 = wave_excl_scan(n5, lane, &tot5);
             const int r11 = wave_excl_scan(n11, lane, &tot11);

@@ -171,6 +171,17 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
                        uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status,
                        const ac3mi_decode_taps *taps);
 
+/* ---- float -> s16 conversion --------------------------------------------------- */
+
+/* Replaces the MMX converters of src/AC3ASM.asm (mmx_convert_N_to_N: psubd 0x43C00000 + packssdw,
+ * :303-318; C twin a52dec-0.7.5-cvs/libao/convert2s16.c:33-41) for whole batches: samples decoded
+ * with bias 384 and level 1 carry their 16-bit value in the low mantissa bits; subtract the constant,
+ * saturate, interleave in WAVE channel order (FL FR FC LFE BL BR; per-flags maps AC3ASM.asm:347-350,
+ * 501-505, 679-684, 854-858, 1083-1094).
+ *   d_planes [n_blocks][n_out][256] float (a52_samples() layout), d_out [n_blocks][256][n_out] s16 */
+int ac3mi_convert_s16_batch(ac3mi_ctx *ctx, const float *d_planes, int16_t *d_out, int flags,
+                            size_t n_blocks);
+
 /* ---- frame encode: PCM -> bitstream ------------------------------------------- */
 
 /* Replaces, for a batch of independent streams, AC3_encode_init + AC3_encode_frame

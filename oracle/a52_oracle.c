@@ -1634,9 +1634,10 @@ int orc_a52_block(orc_a52_t *st)
 
 static inline int16_t to_s16(float f)
 {
+    uint32_t u;
     int32_t i;
-    memcpy(&i, &f, 4);
-    i -= 0x43c00000;
+    memcpy(&u, &f, 4);
+    i = (int32_t)(u - 0x43c00000u);         /* psubd wraps modulo 2^32 */
     return (int16_t)(i > 32767 ? 32767 : i < -32768 ? -32768 : i);
 }
 

@@ -1,0 +1,82 @@
+"""GPU: the reference's per-stream C surface, exercised by a plain-C host program
+(tests/dropin_c/dropin_host.c, compiled with gcc against include/ac3mi_dropin.h and linked to
+libac3mi.so) - the drop-in claim of INTEGRATION.md - and the batched s16 converter (D18)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host_exe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("dropin") / "dropin_host"
+    libdir = os.path.join(H.ROOT, "ac-3-acm-codec_amd")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(H.ROOT, "include"),
+                           os.path.join(H.ROOT, "tests", "dropin_c", "dropin_host.c"), "-o", str(out),
+                           "-L", libdir, "-l:libac3mi.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return str(out)
+
+
+@pytest.mark.parametrize("flags,level,bias,dynoff", [(7 | 16, 1.0, 0.0, 0), (2 | 32, 1.0, 384.0, 1), (7 | 16 | 32, 1.0, 384.0, 0)])
+def test_c_host_decode_loop(host_exe, tmp_path, flags, level, bias, dynoff):
+    frames = H.orc_encode(H.gen_pcm(5, 6, seed=21, kind="tones"))
+    (tmp_path / "in.ac3").write_bytes(frames.tobytes())
+    r = subprocess.run([host_exe, "dec", str(tmp_path / "in.ac3"), str(tmp_path / "o.f32"), str(tmp_path / "o.s16"),
+                        str(flags), str(level), str(bias), str(dynoff)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "frames 5 errors 0" in r.stdout
+    want, errs, oflags = H.orc_decode(frames, flags, level, bias, dynrng_off=bool(dynoff))
+    got = np.fromfile(tmp_path / "o.f32", np.float32).reshape(want.shape)
+    err = got.astype(np.float64) - want
+    tol = 1e-6 if bias == 0 else 4e-5
+    assert H.rms(err) <= tol, H.rms(err)
+    if bias == 384.0:
+        nout = want.shape[2]
+        s16 = np.fromfile(tmp_path / "o.s16", np.int16).reshape(5, 6, 256, nout)
+        L = H.orc()
+        ref16 = np.zeros((256, nout), np.int16)
+        worst = 0
+        for f in range(5):
+            for b in range(6):
+                L.orc_convert_s16(H.P(np.ascontiguousarray(want[f, b]), H.fp), H.P(ref16, H.i16p), oflags)
+                worst = max(worst, int(np.abs(s16[f, b].astype(int) - ref16.astype(int)).max()))
+        assert worst <= 1          # the float PCM may differ by one float32 ulp at bias 384 = one s16 step
+
+
+def test_c_host_encode_loop(host_exe, tmp_path):
+    pcm = H.gen_pcm(4, 6, seed=8, kind="music")
+    (tmp_path / "in.s16").write_bytes(pcm.tobytes())
+    r = subprocess.run([host_exe, "enc", str(tmp_path / "in.s16"), str(tmp_path / "o.ac3"), "48000", "384000", "6"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(tmp_path / "o.ac3", np.uint8).reshape(4, 1536)
+    assert np.array_equal(got, H.orc_encode(pcm))
+
+
+@pytest.mark.parametrize("flags", [1, 2, 10, 3, 4, 5, 6, 7, 1 | 16, 2 | 16, 3 | 16, 4 | 16, 5 | 16, 6 | 16, 7 | 16])
+def test_s16_converter_batch(engine, flags):
+    """ac3mi_convert_s16_batch vs the AC3ASM restatement, incl. saturation on out-of-range floats."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(flags)
+    nout = H.NFCHANS[flags & 15] + (1 if flags & 16 else 0)
+    N = 40
+    x = (384.0 + rng.standard_normal((N, nout, 256)) * 0.6).astype(np.float32)      # some samples clip
+    x[0, 0, :4] = [383.0, 385.0, -1.0, 1e9]
+    want = np.zeros((N, 256, nout), np.int16)
+    L = H.orc()
+    for i in range(N):
+        L.orc_convert_s16(H.P(x[i], H.fp), H.P(want[i], H.i16p), flags)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((N, 256, nout), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    rc = engine.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(engine.ctx), ctypes.c_void_p(d_in.data_ptr()),
+                                            ctypes.c_void_p(d_out.data_ptr()), flags, ctypes.c_size_t(N))
+    assert rc == 0
+    engine.sync()
+    assert np.array_equal(d_out.cpu().numpy(), want)

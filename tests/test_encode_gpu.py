@@ -98,7 +98,9 @@ def test_encode_other_configurations(engine, nch, bitrate, freq):
     pcm = [H.gen_pcm(4, nch, seed=5 + s, kind=("music", "tones", "noise")[s % 3]) for s in range(3)]
     want, _ = _oracle(pcm, nch, bitrate, freq, chmap)
     got, _ = _gpu(engine, pcm, nch, bitrate, freq, chmap, taps=False)
-    assert np.array_equal(got, want), "bitstream differs in %d bytes" % int((got != want).sum())
+    bad = [(s, f, int((got[s, f] != want[s, f]).sum()), int(np.nonzero(got[s, f] != want[s, f])[0][0]))
+           for s in range(got.shape[0]) for f in range(got.shape[1]) if not np.array_equal(got[s, f], want[s, f])]
+    assert not bad, "frames (stream, frame, bytes differing, first byte): %r" % bad
 
 
 def test_encode_state_carries_across_calls(engine):
