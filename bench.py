@@ -103,6 +103,76 @@ def measured_traffic(frames):
     return best
 
 
+def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
+    """Whole-path numbers for the other BASELINE configs on the same batch size (frames resident in HBM):
+    configs[2] encode (s16 PCM -> frames), bitstream decode (frames -> float PCM, both kernels) and
+    decode -> s16 -> re-encode (configs[4]'s per-GPU transcode step).  Each: frames/s of this rank's shard
+    (MAX-reduced time), algorithmic GB/s per SURVEY.md §8d, x realtime."""
+    import torch
+    S = min(S, 65536)
+    enc = pkg.EncodeDesc(48000, 384000, 6)
+    fb = enc.frame_bytes()
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    t = torch.arange(1536, device=dev, dtype=torch.float32)
+    ph = torch.rand((S, 1, 6), device=dev, generator=g) * 6.28
+    fr = 0.01 * torch.arange(1, 7, device=dev, dtype=torch.float32)
+    pcm = 8000.0 * torch.sin(ph + fr * t[None, :, None]) + (torch.rand((S, 1536, 6), device=dev, generator=g) - 0.5) * 4096
+    pcm = pcm.round().clamp(-32768, 32767).to(torch.int16).reshape(S, 1, 1536, 6).contiguous()
+    last = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+    csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
+    frames = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
+    dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=fb)
+    delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+    lfsr = torch.ones((S,), dtype=torch.int16, device=dev)
+    out = torch.empty((S, 1, 6, 6, 256), dtype=torch.float32, device=dev)
+    status = torch.zeros((S, 1), dtype=torch.int32, device=dev)
+    s16 = torch.empty((S, 6 * 256, 6), dtype=torch.int16, device=dev)
+    frames2 = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
+    chmap = (0, 2, 1, 4, 5, 3)
+    import ctypes
+
+    def do_enc(src=pcm, dst=frames):
+        eng.encode_batch(enc, src, chmap, last, csnr, out=dst, wait_torch=False)
+
+    def do_dec():
+        eng.decode_batch(dec, frames, delay, lfsr, out=out, status=status, wait_torch=False)
+
+    def do_cvt():
+        eng._check(eng.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(eng.ctx), ctypes.c_void_p(out.data_ptr()),
+                                                  ctypes.c_void_p(s16.data_ptr()), 7 | 16, ctypes.c_size_t(S * 6)))
+
+    def do_transcode():
+        do_dec()
+        do_cvt()
+        do_enc(s16.view(S, 1, 1536, 6), frames2)
+
+    res = {}
+    for name, fn, nbytes in (("encode", do_enc, 18432 + 1536 + 2 * 3072),
+                             ("decode", do_dec, 1536 + 36864 + 2 * 3072),
+                             ("transcode", do_transcode, 38400 + 19968)):
+        torch.cuda.synchronize(dev)
+        fn()
+        barrier()
+        eng.timer_start()
+        for _ in range(steps):
+            fn()
+        ms = eng.timer_stop() / steps
+        barrier()
+        if dist is not None:
+            tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt[0])
+        fps = S / (ms * 1e-3)
+        res[name] = {"frames_per_s_per_gpu": fps, "ms_per_pass": ms, "algorithmic_GBps": nbytes * fps / 1e9,
+                     "hbm_frac": nbytes * fps / 1e9 / HBM_PEAK_GBS, "realtime_x": fps * 0.032,
+                     "algorithmic_bytes_per_frame": nbytes}
+    ok = int((status & 0x1ff).max().item()) == 0
+    res["decode"]["all_frames_ok"] = ok
+    res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
+                   "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +180,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary decode/encode/transcode timings")
     args = ap.parse_args()
 
     import importlib
@@ -164,6 +235,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
 
+    # ---- secondary timings (not the headline): full frame decode, encode, transcode ----
+    extra = None
+    if not args.no_extra:
+        extra = secondary_timings(pkg, eng, dev, S, rank, dist, barrier)
+
     if rank == 0:
         total_frames = S * world * args.steps
         value = total_frames / dt
@@ -202,6 +278,8 @@ def main():
                 "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
             },
         }
+        if extra is not None:
+            line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         else:
