@@ -153,6 +153,21 @@ def main():
     np.savez_compressed(os.path.join(OUT, "encoder.npz"), pcm_in=pcm_in, frames=frames, mdct=mdct, exponent=expo,
                         encoded_exp=eexp, bap=bap, exp_strategy=strat, exp_samples=shift, snroffst=snr,
                         costab=cos, sintab=sin, xcos1=xc, xsin1=xs, crc_table=crc)
+    # ---- packer streams: coupling, rematrix, delta bit allocation, dynrng, block switching ... --------
+    from tests import packer
+    d = {}
+    for tag, acmod, lfe, fscod, bsid, fsz, flags in (("a7", 7, 1, 0, 8, 36, 7 | 16), ("a7_st", 7, 1, 0, 8, 36, 2 | 32),
+                                                    ("a2", 2, 0, 0, 8, 30, 2), ("a2_mono", 2, 0, 1, 8, 31, 1),
+                                                    ("a0", 0, 0, 2, 8, 28, 0), ("a5_half", 5, 1, 0, 9, 36, 5 | 16),
+                                                    ("a3_dolby", 3, 0, 0, 10, 34, 10)):
+        fr = packer.make_stream(4242 + acmod, 3, acmod, lfe, fscod=fscod, bsid=bsid, frmsizecod=fsz)
+        pcm, errs, oflags = H.ref_decode(fr, flags, 1.0, 0.0)
+        assert errs == 0
+        d["frames_" + tag] = fr
+        d["pcm_" + tag] = pcm
+        d["args_" + tag] = np.array([flags, oflags], np.int32)
+    np.savez_compressed(os.path.join(OUT, "packer.npz"), **d)
+
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)))
