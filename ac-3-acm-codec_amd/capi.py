@@ -4,7 +4,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libac3mi.so")
+LIB_PATH = os.environ.get("AC3MI_LIB") or os.path.join(_HERE, "libac3mi.so")   # override: A/B builds only
 HEADER_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 c_void_p, c_int, c_float, c_size_t, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,

@@ -59,36 +59,27 @@ __device__ __forceinline__ void load_short(const float *plane, int l8, float sig
     }
 }
 
-template <bool MIX>
-__global__ __launch_bounds__(256) void xform_kernel(const XformParams P)
+template <bool MIX, int WPS>
+__global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 {
     __shared__ float2 lds_ex[4 * EX_WAVE];
+    __shared__ float2 lds_twl[128];                 // merged long-block twiddles [lane][k]
+    __shared__ float lds_win[256];                  // KBD window
 
     const int tid = threadIdx.x;
     const int l8 = tid & 7;
     const int group = tid >> 3;                     // 0..31 inside the workgroup
     const int chain = blockIdx.x * 32 + group;
+    // constants shared by the whole workgroup live in LDS (registers are the scarce resource here)
+    if (tid < 128) lds_twl[tid] = P.tw_long[tid];
+    lds_win[tid] = P.window[tid];
+    __syncthreads();
     if (chain >= P.n_chains) return;                // whole 8-lane groups leave together
     float2 *ex = lds_ex + group * EX_GROUP;
+    const float2 *twl = lds_twl + l8 * 16;
 
     const int s = chain / P.n_out;
     const int o = chain - s * P.n_out;
-
-    // lane constants
-    cf twl[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        float2 t = P.tw_long[l8 * 16 + k];
-        twl[k] = {t.x, t.y};
-    }
-    // window taps of the 8 owned i: w[2i], w[2i+1], w[254-2i], w[255-2i]
-    float2 wlo[8], whi[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
-        wlo[j] = *reinterpret_cast<const float2 *>(P.window + 2 * i);
-        whi[j] = *reinterpret_cast<const float2 *>(P.window + 254 - 2 * i);
-    }
     // overlap tail of this chain
     float2 dl[8];
     float *dptr = P.delay + (size_t)chain * 128;
@@ -122,12 +113,7 @@ __global__ __launch_bounds__(256) void xform_kernel(const XformParams P)
                 load_long(cblk + (size_t)o * 256, l8, 1.f, xa, xb);
                 imdct_long(xa, xb, twl, ex, l8, ft);
             } else {
-                cf tws[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    float2 t = P.tw_short[l8 * 16 + k];
-                    tws[k] = {t.x, t.y};
-                }
+                const float2 *tws = P.tw_short + l8 * 16;      // rare path: straight from L1/L2
                 load_short(cblk + (size_t)o * 256, l8, 1.f, xa, xb);
                 imdct_short(xa, xb, tws, ex, l8, ft);
             }
@@ -163,12 +149,7 @@ __global__ __launch_bounds__(256) void xform_kernel(const XformParams P)
                     any = true;
                 }
                 if (any) {
-                    cf tws[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        float2 t = P.tw_short[l8 * 16 + k];
-                        tws[k] = {t.x, t.y};
-                    }
+                    const float2 *tws = P.tw_short + l8 * 16;
                     imdct_short(xa, xb, tws, ex, l8, ft);
                 }
             }
@@ -179,11 +160,13 @@ __global__ __launch_bounds__(256) void xform_kernel(const XformParams P)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+            const float2 wlo = *reinterpret_cast<const float2 *>(&lds_win[2 * i]);         // w[2i], w[2i+1]
+            const float2 whi = *reinterpret_cast<const float2 *>(&lds_win[254 - 2 * i]);   // w[254-2i], w[255-2i]
             float2 lo, hi;
-            lo.x = ft.f0[j] * wlo[j].x + (dl[j].x * whi[j].y + P.bias);    // out[2i]
-            lo.y = ft.f1[j] * wlo[j].y + (dl[j].y * whi[j].x + P.bias);    // out[2i+1]
-            hi.x = dl[j].y * wlo[j].y + P.bias - ft.f1[j] * whi[j].x;      // out[254-2i]
-            hi.y = dl[j].x * wlo[j].x + P.bias - ft.f0[j] * whi[j].y;      // out[255-2i]
+            lo.x = ft.f0[j] * wlo.x + (dl[j].x * whi.y + P.bias);          // out[2i]
+            lo.y = ft.f1[j] * wlo.y + (dl[j].y * whi.x + P.bias);          // out[2i+1]
+            hi.x = dl[j].y * wlo.y + P.bias - ft.f1[j] * whi.x;            // out[254-2i]
+            hi.y = dl[j].x * wlo.x + P.bias - ft.f0[j] * whi.y;            // out[255-2i]
             *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
             *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
             dl[j].x = ft.t0[j];
@@ -223,10 +206,13 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
         }
     if (P.n_chains <= 0 || P.frames <= 0) return hipSuccess;
     const int grid = (P.n_chains + 31) / 32;
+    // 4 workgroups per CU (LDS: 40 KB each); measured on MI355X: 3 vs 4 waves/SIMD, packed vs scalar f32 and
+    // 8- vs 16-byte accesses all land within 1 % - the kernel runs at the rate of a plain copy with the same
+    // addressing (profiles/r01_xform_probes.md)
     if (identity)
-        hipLaunchKernelGGL(xform_kernel<false>, dim3(grid), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, P);
     else
-        hipLaunchKernelGGL(xform_kernel<true>, dim3(grid), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((xform_kernel<true, 2>), dim3(grid), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

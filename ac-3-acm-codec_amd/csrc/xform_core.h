@@ -161,9 +161,13 @@ struct FirstTail {
     float f0[8], f1[8], t0[8], t1[8];
 };
 
+__device__ __forceinline__ cf tw_at(const cf (&tw)[16], int k) { return tw[k]; }
+__device__ __forceinline__ cf tw_at(const float2 *tw, int k) { float2 t = tw[k]; return {t.x, t.y}; }
+
 // Long block.  xa[n1] = X[2m], xb[n1] = X[255-2m], m = 8*n1 + l8.  tw = this lane's
 // 16 merged twiddles.  Accumulates into ft.
-__device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&xb)[16], const cf (&tw)[16],
+template <typename TW>
+__device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&xb)[16], const TW &tw,
                                            float2 *ex, int l8, FirstTail &ft)
 {
     cf v[16], r[16];
@@ -171,7 +175,7 @@ __device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&
     for (int n = 0; n < 16; n++) v[n] = cmul(cf{xa[n], xb[n]}, C32_RE[n], C32_IM[n]);
     dft16(v);
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw[k]);
+    for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw_at(tw, k));
     transpose_8x16(ex, l8, v, r);
     dft8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
     dft8(r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15]);
@@ -196,7 +200,8 @@ __device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&
 
 // Short block.  Lane l8 = 4*f + n2 feeds DFT f (0: even, 1: odd coefficients):
 // xa[n1] = X[16 n1 + 4 n2 + f], xb[n1] = X[254 + f - 16 n1 - 4 n2].
-__device__ __forceinline__ void imdct_short(const float (&xa)[16], const float (&xb)[16], const cf (&tw)[16],
+template <typename TW>
+__device__ __forceinline__ void imdct_short(const float (&xa)[16], const float (&xb)[16], const TW &tw,
                                             float2 *ex, int l8, FirstTail &ft)
 {
     cf v[16], r[16];
@@ -204,7 +209,7 @@ __device__ __forceinline__ void imdct_short(const float (&xa)[16], const float (
     for (int n = 0; n < 16; n++) v[n] = cmul(cf{xa[n], xb[n]}, C32_RE[n], C32_IM[n]);
     dft16(v);
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw[k]);
+    for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw_at(tw, k));
     transpose_8x16(ex, l8, v, r);
     dft4(r[0], r[1], r[2], r[3]);       // Y1[l8+16 k2]
     dft4(r[4], r[5], r[6], r[7]);       // Y2[l8+16 k2]
