@@ -233,18 +233,22 @@ struct PackParams {
     uint32_t crc_inv;           // x^-(16*fs58-16) mod poly (:1627)
     uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
     int c1, c2;                 // CRC chunk bytes per lane
+    int frw;                    // dwords of the LDS frame buffer (frame + 256 bytes headroom for the overshoot quirk)
 };
 
 constexpr int PK_MAXBYTES = 3840 + 256;
 constexpr int PK_FRW = PK_MAXBYTES / 4;
 
+constexpr int G3 = 0, G5 = 384, G11 = 768, GTOT = 1344;    // group slots for <= 1122 coefficients: 374 / 374 / 561
+
 struct PackLDS {
     uint8_t E[36][256];         // exponents, raw then encoded in place   [blk*6+ch]
-    int16_t mask[36][50];
+    int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor once the search starts
+    uint32_t gtab[GTOT];        // per group of the block being packed: code (bits 0..6) | bit offset << 8
     uint8_t bapb[6][256];       // bap of the block being packed
-    uint32_t fr[PK_FRW];        // frame as MSB-first dwords
-    uint16_t gcode[3][768];             // up to 1500/2 groups of the 11-level kind
-    uint16_t goff[3][768];
+    uint32_t *fr;               // frame as MSB-first dwords (dynamic LDS, sized for the frame + headroom)
+    int frw;                    // its length in dwords
+    int8_t shiftv[36];          // exp_samples of the frame
     int diff[6][6];
     uint8_t strat[6][6];
     uint8_t latab[256];
@@ -256,11 +260,11 @@ struct PackLDS {
     uint16_t crc_tab[256];
 };
 
-__device__ __forceinline__ void put_bits(uint32_t *fr, uint32_t pos, int n, uint32_t v)
+__device__ __forceinline__ void put_bits(uint32_t *fr, int frw, uint32_t pos, int n, uint32_t v)
 {
     if (n <= 0) return;
     const uint32_t w = pos >> 5;
-    if (w + 1 >= (uint32_t)PK_FRW) return;
+    if (w + 1 >= (uint32_t)frw) return;
     const uint64_t x = (uint64_t)v << (64 - n - (pos & 31));
     const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
     if (hi) atomicOr(&fr[w], hi);
@@ -281,11 +285,12 @@ __device__ __forceinline__ int lowcomp_step(int a, int b0, int b1, int bin)     
     return a;
 }
 
-// PSD integration, excitation and mask for one (block, channel) - run by ONE lane.  :220-367
+// PSD integration, excitation and mask for one (block, channel) - run by ONE lane, in place in its LDS row:
+// first the band PSDs are written to mask[], then one forward walk turns them into the masking curve
+// (band b only needs bndpsd[b] and bndpsd[b+1], both still intact when b is overwritten).   :220-367
 __device__ void compute_mask_lane(PackLDS &L, const uint8_t *exp, int end, bool is_lfe, int16_t *mask,
                                   int sdecay, int fdecay, int sgain, int dbknee, int fgain, int halfrate)
 {
-    int16_t bndpsd[50], excite[50];
     int j = 0, k = 0, v, lowcomp = 0, fast = 0, slow = 0, begin, end1, bin;
     do {
         v = 3072 - ((int)(int8_t)exp[j] << 7);
@@ -298,41 +303,51 @@ __device__ void compute_mask_lane(PackLDS &L, const uint8_t *exp, int end, bool 
             if (c >= 0) { a = c >> 1; if (a > 255) a = 255; v = v + L.latab[a]; }
             else { a = (-c) >> 1; if (a > 255) a = 255; v = pj + L.latab[a]; }
         }
-        bndpsd[k++] = (int16_t)v;
+        mask[k++] = (int16_t)v;
     } while (end > L.band_start[k]);
 
     const int bndend = L.band_of_bin[end - 1] + 1;
-    lowcomp = lowcomp_step(lowcomp, bndpsd[0], bndpsd[1], 0);
-    excite[0] = (int16_t)(bndpsd[0] - fgain - lowcomp);
-    lowcomp = lowcomp_step(lowcomp, bndpsd[1], bndpsd[2], 1);
-    excite[1] = (int16_t)(bndpsd[1] - fgain - lowcomp);
+    auto finish = [&](int b, int excite, int psd) {                  // masking curve :357-367
+        int v1 = excite;
+        const int t = dbknee - psd;
+        if (t > 0) v1 += t >> 2;
+        const int h = L.hth[b >> halfrate];
+        mask[b] = (int16_t)(v1 > h ? v1 : h);
+    };
+    int p0 = mask[0], p1 = mask[1], p2 = bndend > 2 ? mask[2] : 0;
+    lowcomp = lowcomp_step(lowcomp, p0, p1, 0);
+    const int e0 = (int16_t)(p0 - fgain - lowcomp);
+    lowcomp = lowcomp_step(lowcomp, p1, p2, 1);
+    const int e1 = (int16_t)(p1 - fgain - lowcomp);
+    finish(0, e0, p0);
+    finish(1, e1, p1);
     begin = 7;
+    int cur = p2;                                                   // bndpsd[bin]
     for (bin = 2; bin < 7; bin++) {
-        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
-        fast = bndpsd[bin] - fgain;
-        slow = bndpsd[bin] - sgain;
-        excite[bin] = (int16_t)(fast - lowcomp);
-        if (!(is_lfe && bin == 6) && bndpsd[bin] <= bndpsd[bin + 1]) { begin = bin + 1; break; }
+        const int nxt = (is_lfe && bin == 6) ? 0 : mask[bin + 1];   // bndpsd[bin+1]
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, cur, nxt, bin);
+        fast = cur - fgain;
+        slow = cur - sgain;
+        finish(bin, (int16_t)(fast - lowcomp), cur);
+        const bool stop = !(is_lfe && bin == 6) && cur <= nxt;
+        cur = nxt;
+        if (stop) { begin = bin + 1; break; }
     }
     end1 = bndend > 22 ? 22 : bndend;
     for (bin = begin; bin < end1; bin++) {
-        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, bndpsd[bin], bndpsd[bin + 1], bin);
-        fast -= fdecay; v = bndpsd[bin] - fgain; if (fast < v) fast = v;
-        slow -= sdecay; v = bndpsd[bin] - sgain; if (slow < v) slow = v;
+        const int nxt = (is_lfe && bin == 6) ? 0 : mask[bin + 1];
+        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, cur, nxt, bin);
+        fast -= fdecay; v = cur - fgain; if (fast < v) fast = v;
+        slow -= sdecay; v = cur - sgain; if (slow < v) slow = v;
         v = fast - lowcomp; if (slow > v) v = slow;
-        excite[bin] = (int16_t)v;
+        finish(bin, (int16_t)v, cur);
+        cur = nxt;
     }
     for (bin = 22; bin < bndend; bin++) {
-        fast -= fdecay; v = bndpsd[bin] - fgain; if (fast < v) fast = v;
-        slow -= sdecay; v = bndpsd[bin] - sgain; if (slow < v) slow = v;
-        excite[bin] = (int16_t)(fast > slow ? fast : slow);
-    }
-    for (bin = 0; bin < bndend; bin++) {
-        int v1 = excite[bin];
-        const int t = dbknee - bndpsd[bin];
-        if (t > 0) v1 += t >> 2;
-        v = L.hth[bin >> halfrate];
-        mask[bin] = (int16_t)(v1 > v ? v1 : v);
+        cur = mask[bin];
+        fast -= fdecay; v = cur - fgain; if (fast < v) fast = v;
+        slow -= sdecay; v = cur - sgain; if (slow < v) slow = v;
+        finish(bin, (int16_t)(fast > slow ? fast : slow), cur);
     }
     for (bin = bndend; bin < 50; bin++) mask[bin] = 0;
 }
@@ -361,42 +376,28 @@ __device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
     return 4 + (ng / 3) * 7;
 }
 
-__device__ __forceinline__ int bap_of(const PackLDS &L, int m, int e, int snroffset, int floorv)
+// bap of one coefficient for SNR offset `snroffset` (:393-420) without tables:
+//   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
+//   =>  address = 80 - 4 exp - max(0, (mask - floor - snroffset) >> 5)            (floor = 0x1f0)
+// and baptab (ENC/ac3tab.h:135-143) in closed form:
+//   0 | 1 x5 | 2 x2 | 3 x3 | 4 x2 | 5 x2 | 6..13 x4 each | 14 x8 | 15 x9
+constexpr int RMAX = 18;            // coefficients per lane and block: ceil((5*223 + 7) / 64)
+
+__device__ __forceinline__ int item_bap(int mask_minus_floor, int e, int snroffset)
 {
-    int v = m - snroffset - floorv;
-    if (v < 0) v = 0;
-    v = (v & 0x1fe0) + floorv;
-    int a = ((3072 - ((int)(int8_t)e << 7)) - v) >> 5;
+    int q = (mask_minus_floor - snroffset) >> 5;
+    q = q < 0 ? 0 : q;
+    int a = 80 - 4 * (int)(int8_t)e - q;
     a = a < 0 ? 0 : a > 63 ? 63 : a;
-    return L.baptab[a];
+    const uint64_t lut = 0x0554433322111110ull;                    // a = 0..14, one nibble each
+    const int hi = 6 + ((a - 15) >> 2);
+    return a < 15 ? (int)((lut >> (4 * a)) & 15) : a >= 55 ? 15 : (hi > 14 ? 14 : hi);
 }
 
-// mantissa bits of the whole frame for one SNR offset (:764-845): wave-wide count
-__device__ int mantissa_bits(const PackLDS &L, const PackParams &P, int snroffset, int floorv, int lane)
+// plain (ungrouped) mantissa width of a bap code; 0 for the grouped codes 1, 2, 4 and for 0
+__device__ __forceinline__ int plain_bits(int bp)
 {
-    const int T = P.nfbw * P.nbc + (P.lfe ? 7 : 0);
-    int total = 0;
-    for (int b = 0; b < 6; b++) {
-        int cnt = 0, bits = 0;
-        for (int t = lane; t < T; t += 64) {
-            int ch = t / P.nbc, bin = t - ch * P.nbc;
-            if (ch >= P.nfbw) { ch = P.nfbw; bin = t - P.nfbw * P.nbc; }
-            const int r = b * 6 + ch;
-            const int bp = bap_of(L, L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset, floorv);
-            if (bp == 1) cnt += 1;
-            else if (bp == 2) cnt += 1 << 11;
-            else if (bp == 4) cnt += 1 << 22;
-            else if (bp == 3) bits += 3;
-            else if (bp == 14) bits += 14;
-            else if (bp == 15) bits += 16;
-            else if (bp) bits += bp - 1;
-        }
-        cnt = wave_sum(cnt);
-        bits = wave_sum(bits);
-        const int n1 = cnt & 0x7ff, n2 = (cnt >> 11) & 0x7ff, n4 = (cnt >> 22) & 0x3ff;
-        total += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
-    }
-    return total;
+    return bp == 3 ? 3 : bp == 5 ? 4 : bp == 14 ? 14 : bp == 15 ? 16 : bp >= 6 ? bp - 1 : 0;
 }
 
 __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :1513-1524, poly 0x18005
@@ -453,12 +454,15 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
     return __shfl(crc, 63, 64);
 }
 
-__global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_fr[];
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= P.n_streams) return;
+    L.fr = dyn_fr;
+    L.frw = P.frw;
 
     for (int i = lane; i < 256; i += 64) {
         L.latab[i] = P.tab->latab[i];
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
             if (ch < nch) v = *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane);
             *reinterpret_cast<uint32_t *>(&L.E[r][4 * lane]) = v;
         }
-        for (int i = lane; i < PK_FRW; i += 64) L.fr[i] = 0;
+        for (int i = lane; i < P.frw; i += 64) dyn_fr[i] = 0;
         WAVE_SYNC();
 
         // ---- exponent strategy (:617-669) ----
@@ -595,28 +599,58 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
             frame_bits += 16;
         }
 
-        // ---- SNR offset search, exactly the reference's sequence (:921-967) ----
-        const int budget = 16 * fs - frame_bits;
-        auto fits = [&](int c, int fsn) -> bool {
-            const int so = (((c - 15) << 4) + fsn) << 2;
-            return budget - mantissa_bits(L, P, so, floorv, lane) >= 0;
-        };
-        int csnr = csnr_prev, fsnr = 0;
-        bool failed = false;
-        while (csnr >= 0 && !fits(csnr, 0)) csnr -= 4;
-        if (csnr < 0) failed = true;
-        if (!failed) {
-            while (csnr + 4 <= 63 && fits(csnr + 4, 0)) csnr += 4;
-            while (csnr + 1 <= 63 && fits(csnr + 1, 0)) csnr++;
-            while (fsnr + 4 <= 15 && fits(csnr, fsnr + 4)) fsnr += 4;
-            while (fsnr + 1 <= 15 && fits(csnr, fsnr + 1)) fsnr++;
-            csnr_prev = csnr;
-        } else {
-            // reference: error path keeps the stored offsets and emits the last tried allocation;
-            // out of contract for any supported bit rate - emit offset 0
-            csnr = 0;
-            fsnr = 0;
+        // ---- per-lane view of the coefficient stream: lane owns items [t0, t1) of every block ----
+        const int R = (T + 63) >> 6;
+        const int t0 = lane * R < T ? lane * R : T, t1 = (lane + 1) * R < T ? (lane + 1) * R : T;
+        int ch0 = t0 / nbc, bin0 = t0 - ch0 * nbc;
+        if (ch0 >= nfbw) { ch0 = nfbw; bin0 = t0 - nfbw * nbc; }
+        if (lane < 36) {
+            const int b = lane / 6, ch = lane - 6 * b;
+            L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
         }
+        // masks minus floor, so the search loop saves a subtraction
+        for (int i = lane; i < 36 * 50; i += 64) (&L.mask[0][0])[i] -= (int16_t)floorv;
+        WAVE_SYNC();
+
+        // ---- SNR offset search, exactly the reference's sequence (:921-967), one evaluation site ----
+        const int budget = 16 * fs - frame_bits;
+        int csnr = csnr_prev, fsnr = 0, phase = 0;
+        bool failed = false;
+        while (phase < 5) {
+            int cc = csnr, ff = fsnr;
+            if (phase == 0) { if (csnr < 0) { failed = true; break; } }
+            else if (phase == 1) { if (csnr + 4 > 63) { phase = 2; continue; } cc = csnr + 4; }
+            else if (phase == 2) { if (csnr + 1 > 63) { phase = 3; continue; } cc = csnr + 1; }
+            else if (phase == 3) { if (fsnr + 4 > 15) { phase = 4; continue; } ff = fsnr + 4; }
+            else { if (fsnr + 1 > 15) break; ff = fsnr + 1; }
+            const int so = (((cc - 15) << 4) + ff) << 2;
+            // mantissa bits of the whole frame at this offset (:764-845)
+            int total = 0;
+#pragma unroll 1
+            for (int b = 0; b < 6; b++) {
+                int cnt = 0, bits = 0, ch = ch0, bin = bin0;
+#pragma unroll 2
+                for (int t = t0; t < t1; t++) {
+                    const int r = b * 6 + ch;
+                    const int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], so);
+                    cnt += bp == 1 ? 1 : bp == 2 ? (1 << 11) : bp == 4 ? (1 << 22) : 0;
+                    bits += plain_bits(bp);
+                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
+                }
+                cnt = wave_sum(cnt);
+                bits = wave_sum(bits);
+                const int n1 = cnt & 0x7ff, n2 = (cnt >> 11) & 0x7ff, n4 = (cnt >> 22) & 0x3ff;
+                total += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+            }
+            const bool ok = budget - total >= 0;
+            if (phase == 0) { if (ok) phase = 1; else csnr -= 4; }
+            else if (phase == 1) { if (ok) csnr += 4; else phase = 2; }
+            else if (phase == 2) { if (ok) csnr += 1; else phase = 3; }
+            else if (phase == 3) { if (ok) fsnr += 4; else phase = 4; }
+            else { if (ok) fsnr += 1; else break; }
+        }
+        if (!failed) csnr_prev = csnr;
+        else { csnr = 0; fsnr = 0; }        // reference: error path, out of contract for every supported bit rate
         const int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
         if (P.tap_snr && lane == 0) { P.tap_snr[fidx * 2] = csnr; P.tap_snr[fidx * 2 + 1] = fsnr; }
         if (P.tap_strat && lane < 36) {
@@ -627,7 +661,7 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
         // ---- header (:1113-1147) ----
         uint32_t pos = 0;
         auto put = [&](int n, uint32_t v) {
-            if (lane == 0) put_bits(L.fr, pos, n, v);
+            if (lane == 0) put_bits(L.fr, L.frw, pos, n, v);
             pos += n;
         };
         put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
@@ -659,7 +693,7 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
                     const int k0 = 1 + 3 * g * gs;
                     const int prev = g ? e[k0 - gs] : e[0];
                     const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
-                    put_bits(L.fr, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+                    put_bits(L.fr, L.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
                 }
                 pos += 7 * ng;
                 if (!is_lfe) put(2, 0);
@@ -676,18 +710,16 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
 
             // ---- mantissas ----
             // pass 1: bap of every coefficient of this block, group ranks
-            const int R = (T + 63) >> 6;
-            const int t0 = lane * R < T ? lane * R : T, t1 = (lane + 1) * R < T ? (lane + 1) * R : T;
             int n3 = 0, n5 = 0, n11 = 0;
             for (int t = t0; t < t1; t++) {
                 int ch = t / nbc, bin = t - ch * nbc;
                 if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
                 const int r = b * 6 + ch;
-                const int bp = bap_of(L, L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset, floorv);
+                const int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset);
                 L.bapb[ch][bin] = (uint8_t)bp;
                 n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
             }
-            for (int i = lane; i < 768; i += 64) { L.gcode[0][i] = 0; L.gcode[1][i] = 0; L.gcode[2][i] = 0; }
+            for (int i = lane; i < GTOT; i += 64) L.gtab[i] = 0;
             int tot3, tot5, tot11, totbits;
             const int r3 = wave_excl_scan(n3, lane, &tot3), r5 = wave_excl_scan(n5, lane, &tot5);
             const int r11 = wave_excl_scan(n11, lane, &tot11);
@@ -719,21 +751,24 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
                     const int bp = L.bapb[ch][bin];
                     if (!bp) continue;
                     const int c = md[((size_t)b * nch + ch) * 256 + bin];
-                    const int e = (int)L.E[b * 6 + ch][bin] - (int)sh[b * nch + ch];
+                    const int e = (int)L.E[b * 6 + ch][bin] - (int)L.shiftv[b * 6 + ch];
                     if (bp == 1) {
                         const int v = quant_sym(c, e, 3), m = c3 % 3, g = c3 / 3;
-                        if (m == 0) { L.goff[0][g] = (uint16_t)(off - pos); off += 5; }
-                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[0][g & ~1]), (unsigned)(v * (m == 0 ? 9 : m == 1 ? 3 : 1)) << (16 * (g & 1)));
+                        uint32_t add = (uint32_t)(v * (m == 0 ? 9 : m == 1 ? 3 : 1));
+                        if (m == 0) { add |= (off - pos) << 8; off += 5; }
+                        atomicAdd(&L.gtab[G3 + g], add);
                         c3++;
                     } else if (bp == 2) {
                         const int v = quant_sym(c, e, 5), m = c5 % 3, g = c5 / 3;
-                        if (m == 0) { L.goff[1][g] = (uint16_t)(off - pos); off += 7; }
-                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[1][g & ~1]), (unsigned)(v * (m == 0 ? 25 : m == 1 ? 5 : 1)) << (16 * (g & 1)));
+                        uint32_t add = (uint32_t)(v * (m == 0 ? 25 : m == 1 ? 5 : 1));
+                        if (m == 0) { add |= (off - pos) << 8; off += 7; }
+                        atomicAdd(&L.gtab[G5 + g], add);
                         c5++;
                     } else if (bp == 4) {
                         const int v = quant_sym(c, e, 11), m = c11 & 1, g = c11 >> 1;
-                        if (m == 0) { L.goff[2][g] = (uint16_t)(off - pos); off += 7; }
-                        atomicAdd(reinterpret_cast<unsigned *>(&L.gcode[2][g & ~1]), (unsigned)(v * (m == 0 ? 11 : 1)) << (16 * (g & 1)));
+                        uint32_t add = (uint32_t)(v * (m == 0 ? 11 : 1));
+                        if (m == 0) { add |= (off - pos) << 8; off += 7; }
+                        atomicAdd(&L.gtab[G11 + g], add);
                         c11++;
                     } else {
                         int v, w;
@@ -742,16 +777,16 @@ __global__ __launch_bounds__(64) void enc_pack_kernel(const PackParams P)
                         else if (bp == 14) { v = quant_asym(c, e, 14); w = 14; }
                         else if (bp == 15) { v = quant_asym(c, e, 16); w = 16; }
                         else { v = quant_asym(c, e, bp - 1); w = bp - 1; }
-                        put_bits(L.fr, off, w, (uint32_t)v);
+                        put_bits(L.fr, L.frw, off, w, (uint32_t)v);
                         off += w;
                     }
                 }
             }
             WAVE_SYNC();
             // pass 4: grouped codes
-            for (int g = lane; g < (tot3 + 2) / 3; g += 64) put_bits(L.fr, pos + L.goff[0][g], 5, L.gcode[0][g]);
-            for (int g = lane; g < (tot5 + 2) / 3; g += 64) put_bits(L.fr, pos + L.goff[1][g], 7, L.gcode[1][g]);
-            for (int g = lane; g < (tot11 + 1) / 2; g += 64) put_bits(L.fr, pos + L.goff[2][g], 7, L.gcode[2][g]);
+            for (int g = lane; g < (tot3 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G3 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 5, x & 0xff); }
+            for (int g = lane; g < (tot5 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G5 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 7, x & 0xff); }
+            for (int g = lane; g < (tot11 + 1) / 2; g += 64) { const uint32_t x = L.gtab[G11 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 7, x & 0xff); }
             pos += (uint32_t)totbits;
             if (P.tap_bap) {
                 uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
@@ -870,7 +905,8 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
         P.pw1[k] = h_gf_pow(2, 8u * P.c1 * (1u << k));
         P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
     }
-    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), 0, stream, P);
+    P.frw = (2 * fs + 256 + 3) / 4;
+    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), P.frw * 4, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame
