@@ -233,7 +233,6 @@ struct PackParams {
     uint32_t crc_inv;           // x^-(16*fs58-16) mod poly (:1627)
     uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
     int c1, c2;                 // CRC chunk bytes per lane
-    int frw;                    // dwords of the LDS frame buffer (frame + 256 bytes headroom for the overshoot quirk)
 };
 
 constexpr int PK_MAXBYTES = 3840 + 256;
@@ -246,8 +245,7 @@ struct PackLDS {
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor once the search starts
     uint32_t gtab[GTOT];        // per group of the block being packed: code (bits 0..6) | bit offset << 8
     uint8_t bapb[6][256];       // bap of the block being packed
-    uint32_t *fr;               // frame as MSB-first dwords (dynamic LDS, sized for the frame + headroom)
-    int frw;                    // its length in dwords
+    uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
     int8_t shiftv[36];          // exp_samples of the frame
     int diff[6][6];
     uint8_t strat[6][6];
@@ -260,11 +258,11 @@ struct PackLDS {
     uint16_t crc_tab[256];
 };
 
-__device__ __forceinline__ void put_bits(uint32_t *fr, int frw, uint32_t pos, int n, uint32_t v)
+__device__ __forceinline__ void put_bits(uint32_t *fr, uint32_t pos, int n, uint32_t v)
 {
     if (n <= 0) return;
     const uint32_t w = pos >> 5;
-    if (w + 1 >= (uint32_t)frw) return;
+    if (w + 1 >= (uint32_t)PK_FRW) return;
     const uint64_t x = (uint64_t)v << (64 - n - (pos & 31));
     const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
     if (hi) atomicOr(&fr[w], hi);
@@ -457,12 +455,9 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
 __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_fr[];
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= P.n_streams) return;
-    L.fr = dyn_fr;
-    L.frw = P.frw;
 
     for (int i = lane; i < 256; i += 64) {
         L.latab[i] = P.tab->latab[i];
@@ -496,7 +491,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             if (ch < nch) v = *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane);
             *reinterpret_cast<uint32_t *>(&L.E[r][4 * lane]) = v;
         }
-        for (int i = lane; i < P.frw; i += 64) dyn_fr[i] = 0;
+        for (int i = lane; i < PK_FRW; i += 64) L.fr[i] = 0;
         WAVE_SYNC();
 
         // ---- exponent strategy (:617-669) ----
@@ -629,10 +624,12 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
 #pragma unroll 1
             for (int b = 0; b < 6; b++) {
                 int cnt = 0, bits = 0, ch = ch0, bin = bin0;
-#pragma unroll 2
-                for (int t = t0; t < t1; t++) {
+                // uniform trip count (R is wave-uniform) so that the compiler can batch the LDS reads of 6 items
+#pragma unroll 6
+                for (int k = 0; k < R; k++) {
                     const int r = b * 6 + ch;
-                    const int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], so);
+                    int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], so);
+                    bp = (t0 + k < t1) ? bp : 0;
                     cnt += bp == 1 ? 1 : bp == 2 ? (1 << 11) : bp == 4 ? (1 << 22) : 0;
                     bits += plain_bits(bp);
                     if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
@@ -661,7 +658,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         // ---- header (:1113-1147) ----
         uint32_t pos = 0;
         auto put = [&](int n, uint32_t v) {
-            if (lane == 0) put_bits(L.fr, L.frw, pos, n, v);
+            if (lane == 0) put_bits(L.fr, pos, n, v);
             pos += n;
         };
         put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
@@ -693,7 +690,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                     const int k0 = 1 + 3 * g * gs;
                     const int prev = g ? e[k0 - gs] : e[0];
                     const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
-                    put_bits(L.fr, L.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+                    put_bits(L.fr, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
                 }
                 pos += 7 * ng;
                 if (!is_lfe) put(2, 0);
@@ -709,15 +706,22 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             put(1, 0);
 
             // ---- mantissas ----
+            // All item loops run the wave-uniform trip count R with a validity predicate, so they can be
+            // unrolled and their LDS / HBM reads batched.
             // pass 1: bap of every coefficient of this block, group ranks
             int n3 = 0, n5 = 0, n11 = 0;
-            for (int t = t0; t < t1; t++) {
-                int ch = t / nbc, bin = t - ch * nbc;
-                if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
-                const int r = b * 6 + ch;
-                const int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset);
-                L.bapb[ch][bin] = (uint8_t)bp;
-                n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
+            {
+                int ch = ch0, bin = bin0;
+#pragma unroll 6
+                for (int k = 0; k < R; k++) {
+                    const int r = b * 6 + ch;
+                    int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset);
+                    if (t0 + k < t1) {
+                        L.bapb[ch][bin] = (uint8_t)bp;
+                        n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
+                    }
+                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
+                }
             }
             for (int i = lane; i < GTOT; i += 64) L.gtab[i] = 0;
             int tot3, tot5, tot11, totbits;
@@ -726,67 +730,54 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             // pass 2: widths
             int nbits = 0;
             {
-                int c3 = r3, c5 = r5, c11 = r11;
-                for (int t = t0; t < t1; t++) {
-                    int ch = t / nbc, bin = t - ch * nbc;
-                    if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
-                    const int bp = L.bapb[ch][bin];
-                    if (bp == 1) { if (c3 % 3 == 0) nbits += 5; c3++; }
-                    else if (bp == 2) { if (c5 % 3 == 0) nbits += 7; c5++; }
-                    else if (bp == 4) { if ((c11 & 1) == 0) nbits += 7; c11++; }
-                    else if (bp == 3) nbits += 3;
-                    else if (bp == 14) nbits += 14;
-                    else if (bp == 15) nbits += 16;
-                    else if (bp) nbits += bp - 1;
+                int c3 = r3, c5 = r5, c11 = r11, ch = ch0, bin = bin0;
+#pragma unroll 6
+                for (int k = 0; k < R; k++) {
+                    const int bp = (t0 + k < t1) ? L.bapb[ch][bin] : 0;
+                    nbits += bp == 1 ? (c3 % 3 == 0 ? 5 : 0) : bp == 2 ? (c5 % 3 == 0 ? 7 : 0) : bp == 4 ? ((c11 & 1) == 0 ? 7 : 0)
+                                     : plain_bits(bp);
+                    c3 += bp == 1; c5 += bp == 2; c11 += bp == 4;
+                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
                 }
             }
             uint32_t off = pos + (uint32_t)wave_excl_scan(nbits, lane, &totbits);
             WAVE_SYNC();
-            // pass 3: quantise; plain mantissas go straight into the frame
+            // pass 3: quantise; plain mantissas go straight into the frame, grouped ones are summed per group
             {
-                int c3 = r3, c5 = r5, c11 = r11;
-                for (int t = t0; t < t1; t++) {
-                    int ch = t / nbc, bin = t - ch * nbc;
-                    if (ch >= nfbw) { ch = nfbw; bin = t - nfbw * nbc; }
-                    const int bp = L.bapb[ch][bin];
-                    if (!bp) continue;
-                    const int c = md[((size_t)b * nch + ch) * 256 + bin];
+                int c3 = r3, c5 = r5, c11 = r11, ch = ch0, bin = bin0;
+                const int32_t *mdb = md + (size_t)b * nch * 256;
+#pragma unroll 6
+                for (int k = 0; k < R; k++) {
+                    const bool valid = t0 + k < t1;
+                    const int bp = valid ? L.bapb[ch][bin] : 0;
+                    const int c = bp ? mdb[ch * 256 + bin] : 0;
                     const int e = (int)L.E[b * 6 + ch][bin] - (int)L.shiftv[b * 6 + ch];
-                    if (bp == 1) {
-                        const int v = quant_sym(c, e, 3), m = c3 % 3, g = c3 / 3;
-                        uint32_t add = (uint32_t)(v * (m == 0 ? 9 : m == 1 ? 3 : 1));
-                        if (m == 0) { add |= (off - pos) << 8; off += 5; }
-                        atomicAdd(&L.gtab[G3 + g], add);
-                        c3++;
-                    } else if (bp == 2) {
-                        const int v = quant_sym(c, e, 5), m = c5 % 3, g = c5 / 3;
-                        uint32_t add = (uint32_t)(v * (m == 0 ? 25 : m == 1 ? 5 : 1));
-                        if (m == 0) { add |= (off - pos) << 8; off += 7; }
-                        atomicAdd(&L.gtab[G5 + g], add);
-                        c5++;
-                    } else if (bp == 4) {
-                        const int v = quant_sym(c, e, 11), m = c11 & 1, g = c11 >> 1;
-                        uint32_t add = (uint32_t)(v * (m == 0 ? 11 : 1));
-                        if (m == 0) { add |= (off - pos) << 8; off += 7; }
-                        atomicAdd(&L.gtab[G11 + g], add);
-                        c11++;
-                    } else {
-                        int v, w;
-                        if (bp == 3) { v = quant_sym(c, e, 7); w = 3; }
-                        else if (bp == 5) { v = quant_sym(c, e, 15); w = 4; }
-                        else if (bp == 14) { v = quant_asym(c, e, 14); w = 14; }
-                        else if (bp == 15) { v = quant_asym(c, e, 16); w = 16; }
-                        else { v = quant_asym(c, e, bp - 1); w = bp - 1; }
-                        put_bits(L.fr, L.frw, off, w, (uint32_t)v);
+                    if (bp == 1 || bp == 2 || bp == 4) {
+                        // grouped 3-, 5-, 11-level codes: member m of group g adds weight * value, the first one also the offset
+                        const int levels = bp == 1 ? 3 : bp == 2 ? 5 : 11;
+                        const int per = bp == 4 ? 2 : 3, bits_g = bp == 1 ? 5 : 7;
+                        const int rank = bp == 1 ? c3 : bp == 2 ? c5 : c11;
+                        const int m = rank % per, g = rank / per;
+                        const int v = quant_sym(c, e, levels);
+                        const int w0 = bp == 4 ? levels : levels * levels;              // 9, 25, 11
+                        uint32_t add = (uint32_t)(v * (m == 0 ? w0 : (m == 1 && per == 3) ? levels : 1));
+                        if (m == 0) { add |= (off - pos) << 8; off += bits_g; }
+                        atomicAdd(&L.gtab[(bp == 1 ? G3 : bp == 2 ? G5 : G11) + g], add);
+                        c3 += bp == 1; c5 += bp == 2; c11 += bp == 4;
+                    } else if (bp) {
+                        const int w = plain_bits(bp);
+                        const int v = bp == 3 ? quant_sym(c, e, 7) : bp == 5 ? quant_sym(c, e, 15) : quant_asym(c, e, w);
+                        put_bits(L.fr, off, w, (uint32_t)v);
                         off += w;
                     }
+                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
                 }
             }
             WAVE_SYNC();
             // pass 4: grouped codes
-            for (int g = lane; g < (tot3 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G3 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 5, x & 0xff); }
-            for (int g = lane; g < (tot5 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G5 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 7, x & 0xff); }
-            for (int g = lane; g < (tot11 + 1) / 2; g += 64) { const uint32_t x = L.gtab[G11 + g]; put_bits(L.fr, L.frw, pos + (x >> 8), 7, x & 0xff); }
+            for (int g = lane; g < (tot3 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G3 + g]; put_bits(L.fr, pos + (x >> 8), 5, x & 0xff); }
+            for (int g = lane; g < (tot5 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G5 + g]; put_bits(L.fr, pos + (x >> 8), 7, x & 0xff); }
+            for (int g = lane; g < (tot11 + 1) / 2; g += 64) { const uint32_t x = L.gtab[G11 + g]; put_bits(L.fr, pos + (x >> 8), 7, x & 0xff); }
             pos += (uint32_t)totbits;
             if (P.tap_bap) {
                 uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
@@ -905,8 +896,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
         P.pw1[k] = h_gf_pow(2, 8u * P.c1 * (1u << k));
         P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
     }
-    P.frw = (2 * fs + 256 + 3) / 4;
-    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), P.frw * 4, stream, P);
+    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), 0, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame
