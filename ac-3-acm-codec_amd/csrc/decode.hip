@@ -24,8 +24,6 @@
 
 namespace ac3mi {
 
-constexpr int MAX_FRAME_BYTES = 3840;
-constexpr int FR_WORDS = MAX_FRAME_BYTES / 4 + 4;
 constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dwords, conflict-free across rows
 
 __device__ const uint8_t k_nfchans[11] = {2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2};
@@ -40,17 +38,14 @@ __device__ const uint16_t k_kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 16
 
 // channel slots: 0..4 = fbw, 5 = lfe, 6 = coupling channel
 struct DecLDS {
-    uint32_t fr[FR_WORDS];
     uint8_t exp[7][ROW];
     int8_t bap[7][ROW];
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
-    float plane[6][256];                  // 0..4 fbw, 5 = lfe
-    uint16_t goff[3][768];                // bit offset of the first member of each 3/5/11-level group (<= 744)
+    uint8_t gcode[3][128];                // open 3/5/11-level codes, indexed by group number mod 128
     uint8_t cplbnd[20];                   // coupling sub-band -> band
     int16_t seg_base[9];                  // mantissa stream segments
     uint8_t seg_ch[8], seg_start[8];
-    float qlev[48];                       // 3-, 5-, 7-, 11-, 15-level dequantiser values
     int8_t la_neg[256];
     uint16_t hth[50];
     int8_t width[64];
@@ -59,21 +54,27 @@ struct DecLDS {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// n in 1..32: the n bits starting at bit `pos`
-__device__ __forceinline__ uint32_t peek(const uint32_t *fr, uint32_t pos, int n)
+// the staged frame: byte-swapped dwords in dynamic LDS, frame_bytes/4 (rounded up) + 4 zero words
+struct FrameBits {
+    const uint32_t *w;
+    uint32_t last;          // highest index a 2-dword read may start at
+};
+
+// n in 1..32: the n bits starting at bit `pos` (reads past the padding return the padding)
+__device__ __forceinline__ uint32_t peek(const FrameBits fr, uint32_t pos, int n)
 {
     uint32_t w = pos >> 5;
-    w = w < (uint32_t)(FR_WORDS - 2) ? w : (uint32_t)(FR_WORDS - 2);
-    const uint64_t v = ((uint64_t)fr[w] << 32) | fr[w + 1];
+    w = w < fr.last ? w : fr.last;
+    const uint64_t v = ((uint64_t)fr.w[w] << 32) | fr.w[w + 1];
     return (uint32_t)((v << (pos & 31)) >> (64 - n));
 }
-__device__ __forceinline__ int32_t speek(const uint32_t *fr, uint32_t pos, int n)
+__device__ __forceinline__ int32_t speek(const FrameBits fr, uint32_t pos, int n)
 {
     return ((int32_t)(peek(fr, pos, n) << (32 - n))) >> (32 - n);
 }
 
 struct Rd {                                   // wave-uniform serial reader
-    const uint32_t *fr;
+    FrameBits fr;
     uint32_t pos;
     __device__ __forceinline__ uint32_t get(int n)
     {
@@ -102,6 +103,20 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     }
     return v;
 }
+
+// wavefront inclusive prefix sum on the DPP network: four steps inside each row of 16, then
+// row 0/2 totals into rows 1/3, then the lower half's total into the upper half
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ uint32_t rfl_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 // stream-persistent decoder fields (wave-uniform)
 struct St {
@@ -141,7 +156,7 @@ struct DecodeParams {
 // ---------------------------------------------------------------------------
 // exponents: L52/parse.c:218-270.  ngrps groups of 7 bits at `pos`; returns 1 on a
 // reserved code or an exponent outside 0..24.
-__device__ int read_exponents(const uint32_t *fr, uint32_t pos, int strategy, int ngrps, int absexp,
+__device__ int read_exponents(const FrameBits fr, uint32_t pos, int strategy, int ngrps, int absexp,
                               uint8_t *dst, int lane)
 {
     const int rep = 1 << (strategy - 1);
@@ -279,32 +294,16 @@ __device__ void bit_allocate_lane(const DecLDS &L, BaCtx c, int bndstart, int st
 // ---------------------------------------------------------------------------
 // mantissa helpers
 
-__device__ __forceinline__ int item_bits_plain(int w) { return w > 0 ? w : 0; }   // widths 3,4,5..16; grouped/zero: 0
-
-// dequantised value of a non-grouped, non-zero mantissa of width w at bit offset off
-__device__ __forceinline__ float plain_value(const DecLDS &L, int w, uint32_t off)
+// Symmetric n-level dequantiser (n = 3, 5, 7, 11, 15; L52/parse.c:272-308 q_1..q_5): level idx is
+// round(32768 * (2*idx - (n-1)) / n).  The product below is within 0.01 of that quotient, whose
+// fractional part is at least 1/(2n) away from one half, so the rounding reproduces the table.
+__device__ __forceinline__ float level_value(int idx, int n, float scale)
 {
-    if (w == 3) return L.qlev[8 + peek(L.fr, off, 3)];
-    if (w == 4) return L.qlev[27 + peek(L.fr, off, 4)];
-    return (float)(speek(L.fr, off, w) * (1 << (16 - w)));
+    return __builtin_rintf((float)(2 * idx - (n - 1)) * scale);
 }
 
-// member m (0 = first) of the grouped code `code` of kind k (0: 3-level/5 bits, 1: 5-level/7 bits, 2: 11-level/7 bits)
-__device__ __forceinline__ float group_value(const DecLDS &L, int kind, int code, int m)
-{
-    if (kind == 0) {
-        if (code >= 27) return 0.f;
-        const int idx = m == 0 ? code / 9 : m == 1 ? (code / 3) % 3 : code % 3;
-        return L.qlev[idx];
-    }
-    if (kind == 1) {
-        if (code >= 125) return 0.f;
-        const int idx = m == 0 ? code / 25 : m == 1 ? (code / 5) % 5 : code % 5;
-        return L.qlev[3 + idx];
-    }
-    if (code >= 121) return 0.f;
-    return L.qlev[16 + (m == 0 ? code / 11 : code % 11)];
-}
+// exact a / d for 0 <= a < 128, 1 <= d <= 25 (d given as 1.0f/d)
+__device__ __forceinline__ int small_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
 __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t idx0, int k)
 {
@@ -320,6 +319,8 @@ __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t 
 __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
 {
     __shared__ DecLDS L;
+    extern __shared__ uint32_t frw[];
+    const FrameBits FB{frw, (uint32_t)((P.frame_bytes + 3) >> 2) + 2u};
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= P.n_streams) return;
@@ -329,7 +330,6 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     if (lane < 50) L.hth[lane] = 0;
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
-    if (lane < 48) L.qlev[lane] = P.tab->qlev[lane];
     for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
     for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
         {
             const int nw = (P.frame_bytes + 3) >> 2;
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-            for (int i = lane; i < FR_WORDS; i += 64) {
+            for (int i = lane; i < nw + 4; i += 64) {
                 uint32_t v = 0;
                 if (i < nw) {
                     v = s32[i];
@@ -369,18 +369,18 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                     if (rem < 4) v &= (1u << (8 * rem)) - 1u;
                     v = __builtin_bswap32(v);
                 }
-                L.fr[i] = v;
+                frw[i] = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        Rd rd{L.fr, 0};
+        Rd rd{FB, 0};
         // ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205) ----
         bool hdr_ok = true;
         {
-            const uint32_t w0 = rfl(L.fr[0]), w1 = rfl(L.fr[1]);
+            const uint32_t w0 = rfl(frw[0]), w1 = rfl(frw[1]);
             const int b4 = (w1 >> 24) & 0xff, b5 = (w1 >> 16) & 0xff, b6 = (w1 >> 8) & 0xff;
             if ((w0 >> 16) != 0x0b77) hdr_ok = false;
             if (b5 >= 0x60) hdr_ok = false;
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
         bool frame_dead = !hdr_ok;
         for (int blk = 0; blk < 6; blk++) {
             float *cblk = cout + (size_t)blk * P.n_in * 256;
+            const int in_lfe = P.lfeon ? 1 : 0;
             int err = frame_dead ? 1 : 0;
             int blkswm = 0, dithmask = 0;
             float gain[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                     const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
                     const int e0 = rd.get(4) << 1;
                     redo = 64;
-                    if (read_exponents(L.fr, rd.pos, cplexpstr, ngrp, e0, &L.exp[6][st.cplstrtmant], lane)) { err = 1; break; }
+                    if (read_exponents(FB, rd.pos, cplexpstr, ngrp, e0, &L.exp[6][st.cplstrtmant], lane)) { err = 1; break; }
                     rd.pos += 7 * ngrp;
                 }
 #pragma unroll
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                         redo |= 1 << i;
                         const int e0 = rd.get(4);
                         if (lane == 0) L.exp[i][0] = (uint8_t)e0;
-                        if (read_exponents(L.fr, rd.pos, es, ngrp, e0, &L.exp[i][1], lane)) err = 1;
+                        if (read_exponents(FB, rd.pos, es, ngrp, e0, &L.exp[i][1], lane)) err = 1;
                         rd.pos += 7 * ngrp;
                         rd.get(2);                                          // gainrng
                     }
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                     redo |= 32;
                     const int e0 = rd.get(4);
                     if (lane == 0) L.exp[5][0] = (uint8_t)e0;
-                    if (read_exponents(L.fr, rd.pos, lfeexpstr, 2, e0, &L.exp[5][1], lane)) { err = 1; break; }
+                    if (read_exponents(FB, rd.pos, lfeexpstr, 2, e0, &L.exp[5][1], lane)) { err = 1; break; }
                     rd.pos += 14;
                 }
 
@@ -701,133 +702,122 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-                const int R = (total + 63) >> 6;
-                const int t0 = lane * R < total ? lane * R : total;
-                const int t1 = (lane + 1) * R < total ? (lane + 1) * R : total;
                 const int ncpl_dith = __popc(st.chincpl & dithmask);
-
-                // pass 1: grouped-code ranks and dither draws
-                int n3 = 0, n5 = 0, n11 = 0, nd = 0;
-                {
-                    int k = 0;
-                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
-                    for (int t = t0; t < t1; t++) {
-                        while (t >= L.seg_base[k + 1]) k++;
-                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
-                        const int w = L.bap[ch][bin];
-                        n3 += w == -1; n5 += w == -2; n11 += w == -3;
-                        if (w == 0) nd += ch == 6 ? ncpl_dith : (ch < 5 ? ((dithmask >> ch) & 1) : 0);
-                    }
-                }
-                const int r3 = wave_incl_scan(n3, lane) - n3, r5 = wave_incl_scan(n5, lane) - n5;
-                const int r11 = wave_incl_scan(n11, lane) - n11;
-                const int rdi = wave_incl_scan(nd, lane);
-                const int rd0 = rdi - nd, nd_total = __shfl(rdi, 63, 64);
-
-                // pass 2: bits per lane
-                int nbits = 0;
-                {
-                    int k = 0, c3 = r3, c5 = r5, c11 = r11;
-                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
-                    for (int t = t0; t < t1; t++) {
-                        while (t >= L.seg_base[k + 1]) k++;
-                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
-                        const int w = L.bap[ch][bin];
-                        if (w > 0) nbits += w;
-                        else if (w == -1) { if (c3 % 3 == 0) nbits += 5; c3++; }
-                        else if (w == -2) { if (c5 % 3 == 0) nbits += 7; c5++; }
-                        else if (w == -3) { if ((c11 & 1) == 0) nbits += 7; c11++; }
-                    }
-                }
-                const int bi = wave_incl_scan(nbits, lane);
-                const uint32_t mant_pos = rd.pos;
-                uint32_t off = mant_pos + (uint32_t)(bi - nbits);
-                rd.pos = mant_pos + (uint32_t)__shfl(bi, 63, 64);
-
                 const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
                 const bool lfsr_live = st.lfsr != 0;
 
-                // pass 3: plain mantissas, zeros/dither, first members' offsets
-                {
-                    int k = 0, c3 = r3, c5 = r5, c11 = r11, cd = rd0;
-                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
-                    for (int t = t0; t < t1; t++) {
-                        while (t >= L.seg_base[k + 1]) k++;
-                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
-                        const int w = L.bap[ch][bin];
+                // One pass, 64 consecutive coefficients of a segment per step.  Two packed wavefront
+                // scans per step: grouped-code ranks (who opens a 5/7-bit code), then bit offsets and
+                // dither draw indices.  The lane that opens a code publishes it in L.gcode for the
+                // one or two members that follow (same step or a later one; groups run across
+                // channels: parse.c:815).
+                uint32_t bitbase = rd.pos;
+                int b3 = 0, b5 = 0, b11 = 0, dbase = 0;
+                const int remat_end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
+                for (int k = 0; k < nseg; k++) {
+                    const int ch = (int)rfl(L.seg_ch[k]), start = (int)rfl(L.seg_start[k]);
+                    const int len = (int)rfl((uint32_t)(L.seg_base[k + 1] - L.seg_base[k]));
+                    float g = 0.f;
+                    int draws = 0;
+                    const bool remat1 = ch == 1 && st.acmod == 2 && st.rematflg != 0;
+                    if (ch < 5) {
+                        g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
+                        draws = (dithmask >> ch) & 1;
+                    } else if (ch == 5) {
+                        g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+                    } else {
+                        draws = ncpl_dith;
+                    }
+                    for (int i0 = 0; i0 < len; i0 += 64) {
+                        const bool act = i0 + lane < len;
+                        const int bin = start + (act ? i0 + lane : 0);
+                        const int w = act ? (int)L.bap[ch][bin] : -9;
                         const int e = L.exp[ch][bin];
-                        if (w == -1) { if (c3 % 3 == 0) { L.goff[0][c3 / 3] = (uint16_t)(off - mant_pos); off += 5; } c3++; continue; }
-                        if (w == -2) { if (c5 % 3 == 0) { L.goff[1][c5 / 3] = (uint16_t)(off - mant_pos); off += 7; } c5++; continue; }
-                        if (w == -3) { if ((c11 & 1) == 0) { L.goff[2][c11 >> 1] = (uint16_t)(off - mant_pos); off += 7; } c11++; continue; }
-                        if (ch < 5) {
-                            const float g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
-                            const float fac = sf_of(e) * g;
-                            float v;
-                            if (w == 0) {
-                                if ((dithmask >> ch) & 1) { v = (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0) * fac; cd++; }
-                                else v = 0.f;
-                            } else { v = plain_value(L, w, off) * fac; off += w; }
-                            L.plane[ch][bin] = v;
-                        } else if (ch == 5) {
-                            const float g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
-                            const float fac = sf_of(e) * g;
-                            float v = 0.f;
-                            if (w != 0) { v = plain_value(L, w, off) * fac; off += w; }
-                            L.plane[5][bin] = v;
+                        const int kind = w == -1 ? 0 : w == -2 ? 1 : w == -3 ? 2 : -1;
+                        const uint32_t gcnt = kind < 0 ? 0u : 1u << (8 * kind);
+                        const uint32_t gincl = wave_incl_scan_u32(gcnt);
+                        const uint32_t gexcl = gincl - gcnt;
+                        const int rank = kind == 0 ? b3 + (int)(gexcl & 255u)
+                                       : kind == 1 ? b5 + (int)((gexcl >> 8) & 255u)
+                                                   : b11 + (int)(gexcl >> 16);
+                        const int per = kind == 2 ? 2 : 3;
+                        const int grp = rank / per, mem = rank - grp * per;
+                        const bool opens = kind >= 0 && mem == 0;
+                        const int nb = w > 0 ? w : opens ? (kind == 0 ? 5 : 7) : 0;
+                        const int nd = w == 0 ? draws : 0;
+                        const uint32_t bcnt = (uint32_t)nb | ((uint32_t)nd << 16);
+                        const uint32_t bincl = wave_incl_scan_u32(bcnt);
+                        const uint32_t off = bitbase + (bincl & 0xffffu) - (uint32_t)nb;
+                        int cd = dbase + (int)(bincl >> 16) - nd;
+                        const uint32_t gtot = rfl_last(gincl), btot = rfl_last(bincl);
+
+                        uint32_t raw = 0;
+                        if (nb) raw = peek(FB, off, nb);
+                        if (opens) L.gcode[kind][grp & 127] = (uint8_t)raw;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                        // levels: 3/5/11-level codes hold 3/3/2 base-n digits; bap 3 and 4 are 7 and 15 levels
+                        float q = 0.f;
+                        {
+                            const int n = kind == 0 ? 3 : kind == 1 ? 5 : kind == 2 ? 11 : w == 3 ? 7 : 15;
+                            const float scale = kind == 0 ? 32768.f / 3 : kind == 1 ? 32768.f / 5 : kind == 2 ? 32768.f / 11
+                                              : w == 3 ? 32768.f / 7 : 32768.f / 15;
+                            int idx = (int)raw;
+                            bool valid = true;
+                            if (kind >= 0) {
+                                const int code = L.gcode[kind][grp & 127];
+                                const float invn = kind == 0 ? 1.f / 3 : kind == 1 ? 1.f / 5 : 1.f / 11;
+                                // digit `mem` of the code: (code / n^(per-1-mem)) % n
+                                const int up = per - 1 - mem;
+                                const float invd = up == 0 ? 1.f : up == 1 ? invn : (kind == 0 ? 1.f / 9 : 1.f / 25);
+                                const int t = small_div(code, invd);
+                                idx = t - n * small_div(t, invn);
+                                valid = code < (kind == 0 ? 27 : kind == 1 ? 125 : 121);
+                            }
+                            else valid = idx < n;                          // 3- and 4-bit codes 7 and 15 decode to 0
+                            if (kind >= 0 || w == 3 || w == 4) q = valid ? level_value(idx, n, scale) : 0.f;
+                            else if (w > 0) q = (float)((((int32_t)(raw << (32 - w))) >> (32 - w)) * (1 << (16 - w)));
+                        }
+
+                        if (ch < 6) {
+                            if (w == 0 && draws) q = (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0);
+                            float v = q * (sf_of(e) * g);
+                            float *dst = cblk + (ch == 5 ? 0 : ch + in_lfe) * 256 + bin;
+                            if (remat1 && act && bin >= 13 && bin < remat_end) {
+                                // rematrix: parse.c:837-865.  Channel 0's bin was stored by this same lane.
+                                const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
+                                if ((st.rematflg >> band) & 1) {
+                                    const float a = dst[-256];
+                                    dst[-256] = a + v;
+                                    v = a - v;
+                                }
+                            }
+                            if (act) *dst = v;
                         } else {
                             // coupling channel: parse.c:435-556
                             const int bnd = L.cplbnd[(bin - st.cplstrtmant) / 12];
-                            float m = 0.f;
-                            if (w != 0) { m = plain_value(L, w, off); off += w; m *= sf_of(e); }
-                            for (int c = 0; c < nf; c++)
-                                if ((st.chincpl >> c) & 1) {
-                                    const float g = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
-                                    const float co = L.cplco[c][bnd] * g;
-                                    float v;
-                                    if (w == 0) {
-                                        if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0); cd++; }
-                                        else v = 0.f;
-                                    } else v = m * co;
-                                    L.plane[c][bin] = v;
-                                }
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-                // pass 4: grouped mantissas
-                {
-                    int k = 0, c3 = r3, c5 = r5, c11 = r11;
-                    while (k + 1 < nseg && t0 >= L.seg_base[k + 1]) k++;
-                    for (int t = t0; t < t1; t++) {
-                        while (t >= L.seg_base[k + 1]) k++;
-                        const int ch = L.seg_ch[k], bin = L.seg_start[k] + (t - L.seg_base[k]);
-                        const int w = L.bap[ch][bin];
-                        if (w > -1 || w < -3) continue;
-                        float q;
-                        if (w == -1) { q = group_value(L, 0, (int)peek(L.fr, mant_pos + L.goff[0][c3 / 3], 5), c3 % 3); c3++; }
-                        else if (w == -2) { q = group_value(L, 1, (int)peek(L.fr, mant_pos + L.goff[1][c5 / 3], 7), c5 % 3); c5++; }
-                        else { q = group_value(L, 2, (int)peek(L.fr, mant_pos + L.goff[2][c11 >> 1], 7), c11 & 1); c11++; }
-                        const int e = L.exp[ch][bin];
-                        if (ch < 5) {
-                            const float g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
-                            L.plane[ch][bin] = q * (sf_of(e) * g);
-                        } else if (ch == 5) {
-                            const float g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
-                            L.plane[5][bin] = q * (sf_of(e) * g);
-                        } else {
-                            const int bnd = L.cplbnd[(bin - st.cplstrtmant) / 12];
                             const float m = q * sf_of(e);
-                            for (int c = 0; c < nf; c++)
-                                if ((st.chincpl >> c) & 1) {
-                                    const float g = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
-                                    L.plane[c][bin] = m * (L.cplco[c][bnd] * g);
+                            for (int c = 0; c < nf; c++) {
+                                if (!((st.chincpl >> c) & 1)) continue;
+                                const float gc = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
+                                const float co = L.cplco[c][bnd] * gc;
+                                float v = m * co;
+                                if (w == 0) {
+                                    v = 0.f;
+                                    if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0); cd++; }
                                 }
+                                if (act) cblk[(c + in_lfe) * 256 + bin] = v;
+                            }
                         }
+                        b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
+                        bitbase += btot & 0xffffu;
+                        dbase += (int)(btot >> 16);
                     }
                 }
+                rd.pos = bitbase;
+                const int nd_total = dbase;
                 // advance the dither generator past this block's draws
                 if (lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
 
@@ -836,41 +826,17 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                 for (int c = 0; c < 5; c++) {
                     if (c >= nf) continue;
                     const int from = ((st.chincpl >> c) & 1) ? st.cplendmant : st.endmant[c];
-                    for (int i = from + lane; i < 256; i += 64) L.plane[c][i] = 0.f;
+                    for (int i = from + lane; i < 256; i += 64) cblk[(c + in_lfe) * 256 + i] = 0.f;
                 }
-                if (st.lfeon) for (int i = 7 + lane; i < 256; i += 64) L.plane[5][i] = 0.f;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-                // rematrix: parse.c:837-865
-                if (st.acmod == 2 && st.rematflg) {
-                    const int end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
-                    for (int i = 0; i < 4; i++) {
-                        if (!((st.rematflg >> i) & 1)) continue;
-                        const int lo = k_remat_edge[i], hi = k_remat_edge[i + 1] < end ? k_remat_edge[i + 1] : end;
-                        for (int j = lo + lane; j < hi; j += 64) {
-                            const float a = L.plane[0][j], b = L.plane[1][j];
-                            L.plane[0][j] = a + b;
-                            L.plane[1][j] = a - b;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
+                if (st.lfeon) for (int i = 7 + lane; i < 256; i += 64) cblk[i] = 0.f;
             }
 
-            // ---- write the block's planes (zeros for a failed block) ----
+            // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
             {
-                const int in_lfe = P.lfeon ? 1 : 0;
-                for (int c = 0; c < P.n_in; c++) {
-                    const int src_plane = (in_lfe && c == 0) ? 5 : c - in_lfe;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!err) v = *reinterpret_cast<const float4 *>(&L.plane[src_plane][4 * lane]);
-                    *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = v;
-                }
+                if (err)
+                    for (int c = 0; c < P.n_in; c++)
+                        *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (P.blksw && lane < P.nfchans)
                     P.blksw[(fidx * 6 + blk) * P.nfchans + lane] = (uint8_t)(err ? 0 : ((blkswm >> lane) & 1));
             }
@@ -912,7 +878,8 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     P.nfchans = nfch[L.acmod & 7];
     P.n_in = P.nfchans + (L.lfeon ? 1 : 0);
     if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_kernel, dim3(L.n_streams), dim3(64), 0, stream, P);
+    const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 4) * 4;
+    hipLaunchKernelGGL(decode_kernel, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
     return hipGetLastError();
 }
 
