@@ -21,6 +21,7 @@
 // Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
 #include "ac3mi_internal.h"
 #include "a52_levels.h"
+#include "wave_ops.h"
 
 namespace ac3mi {
 
@@ -93,30 +94,7 @@ struct Rd {                                   // wave-uniform serial reader
 
 __device__ __forceinline__ float sf_of(int e) { return __int_as_float((127 - 15 - e) << 23); }   // 2^-(15+e)
 
-// wavefront inclusive prefix sum
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// wavefront inclusive prefix sum on the DPP network: four steps inside each row of 16, then
-// row 0/2 totals into rows 1/3, then the lower half's total into the upper half
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-__device__ __forceinline__ uint32_t rfl_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ int wave_incl_scan(int v, int) { return (int)wave_incl_scan_u32((uint32_t)v); }
 
 // stream-persistent decoder fields (wave-uniform)
 struct St {
@@ -749,7 +727,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                         const uint32_t bincl = wave_incl_scan_u32(bcnt);
                         const uint32_t off = bitbase + (bincl & 0xffffu) - (uint32_t)nb;
                         int cd = dbase + (int)(bincl >> 16) - nd;
-                        const uint32_t gtot = rfl_last(gincl), btot = rfl_last(bincl);
+                        const uint32_t gtot = wave_last(gincl), btot = wave_last(bincl);
 
                         uint32_t raw = 0;
                         if (nb) raw = peek(FB, off, nb);

@@ -18,6 +18,7 @@
 // Integer arithmetic only (no -ffast-math dependence); the Q15 tables come from the host (capi.hip)
 // with the reference's expressions.
 #include "ac3mi_internal.h"
+#include "wave_ops.h"
 
 namespace ac3mi {
 
@@ -36,23 +37,7 @@ __device__ __forceinline__ int wave_or(int v)
     for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
     return v;
 }
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
-{
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(x, d, 64);
-        if (lane >= d) x += t;
-    }
-    *total = __shfl(x, 63, 64);
-    return x - v;
-}
+__device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint32_t)v); }
 
 // ---------------------------------------------------------------------------------------------
 // kernel 1: window + normalise + MDCT + exponents
@@ -238,13 +223,12 @@ struct PackParams {
 constexpr int PK_MAXBYTES = 3840 + 256;
 constexpr int PK_FRW = PK_MAXBYTES / 4;
 
-constexpr int G3 = 0, G5 = 384, G11 = 768, GTOT = 1344;    // group slots for <= 1122 coefficients: 374 / 374 / 561
 
 struct PackLDS {
     uint8_t E[36][256];         // exponents, raw then encoded in place   [blk*6+ch]
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor once the search starts
-    uint32_t gtab[GTOT];        // per group of the block being packed: code (bits 0..6) | bit offset << 8
-    uint8_t bapb[6][256];       // bap of the block being packed
+    uint32_t gtab[3][128];      // 3/5/11-level codes being assembled: code (bits 0..6) | bit offset << 8
+    uint32_t bitlut[64];        // see lut_index
     uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
     int8_t shiftv[36];          // exp_samples of the frame
     int diff[6][6];
@@ -374,22 +358,21 @@ __device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
     return 4 + (ng / 3) * 7;
 }
 
-// bap of one coefficient for SNR offset `snroffset` (:393-420) without tables:
+// bap of one coefficient for SNR offset `snroffset` (:393-420):
 //   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
-//   =>  address = 80 - 4 exp - max(0, (mask - floor - snroffset) >> 5)            (floor = 0x1f0)
-// and baptab (ENC/ac3tab.h:135-143) in closed form:
-//   0 | 1 x5 | 2 x2 | 3 x3 | 4 x2 | 5 x2 | 6..13 x4 each | 14 x8 | 15 x9
-constexpr int RMAX = 18;            // coefficients per lane and block: ceil((5*223 + 7) / 64)
+//   =>  address = clamp(80 - 4 exp - max(0, (mask - floor - snroffset) >> 5), 0, 63)       (floor = 0x1f0)
+// L.bitlut[address] = plain mantissa width | (bap==1) << 10 | (bap==2) << 16 | (bap==4) << 22 | bap << 28.
+// lut_index returns the address with d4 = 4 * (80 - 4 exp) (hugely negative for a padding item: address 0,
+// bap 0, no bits).
+constexpr int RT = 18;              // coefficients per lane and block: ceil((5*223 + 7) / 64)
 
-__device__ __forceinline__ int item_bap(int mask_minus_floor, int e, int snroffset)
+__device__ __forceinline__ int lut_index(int d4, int mask_minus_floor, int snroffset)
 {
-    int q = (mask_minus_floor - snroffset) >> 5;
-    q = q < 0 ? 0 : q;
-    int a = 80 - 4 * (int)(int8_t)e - q;
-    a = a < 0 ? 0 : a > 63 ? 63 : a;
-    const uint64_t lut = 0x0554433322111110ull;                    // a = 0..14, one nibble each
-    const int hi = 6 + ((a - 15) >> 2);
-    return a < 15 ? (int)((lut >> (4 * a)) & 15) : a >= 55 ? 15 : (hi > 14 ? 14 : hi);
+    int q4 = ((mask_minus_floor - snroffset) >> 3) & ~3;
+    q4 = q4 < 0 ? 0 : q4;
+    int a4 = d4 - q4;
+    a4 = a4 < 0 ? 0 : a4 > 252 ? 252 : a4;
+    return a4 >> 2;
 }
 
 // plain (ungrouped) mantissa width of a bap code; 0 for the grouped codes 1, 2, 4 and for 0
@@ -397,6 +380,33 @@ __device__ __forceinline__ int plain_bits(int bp)
 {
     return bp == 3 ? 3 : bp == 5 ? 4 : bp == 14 ? 14 : bp == 15 ? 16 : bp >= 6 ? bp - 1 : 0;
 }
+
+// The reference's SNR-offset search (:921-967) as a resumable state machine: next() skips the steps that
+// need no evaluation and names the next (csnroffst, fsnroffst) to try, consume() takes the verdict.
+struct SnrSearch {
+    int csnr, fsnr, phase;
+    bool failed;
+    __device__ __forceinline__ bool next(int &cc, int &ff)
+    {
+        for (;;) {
+            cc = csnr; ff = fsnr;
+            if (phase == 0) { if (csnr < 0) { failed = true; phase = 5; return false; } return true; }
+            if (phase == 1) { if (csnr + 4 > 63) { phase = 2; continue; } cc = csnr + 4; return true; }
+            if (phase == 2) { if (csnr + 1 > 63) { phase = 3; continue; } cc = csnr + 1; return true; }
+            if (phase == 3) { if (fsnr + 4 > 15) { phase = 4; continue; } ff = fsnr + 4; return true; }
+            if (phase == 4) { if (fsnr + 1 > 15) { phase = 5; return false; } ff = fsnr + 1; return true; }
+            return false;
+        }
+    }
+    __device__ __forceinline__ void consume(bool ok)
+    {
+        if (phase == 0) { if (ok) phase = 1; else csnr -= 4; }
+        else if (phase == 1) { if (ok) csnr += 4; else phase = 2; }
+        else if (phase == 2) { if (ok) csnr += 1; else phase = 3; }
+        else if (phase == 3) { if (ok) fsnr += 4; else phase = 4; }
+        else if (phase == 4) { if (ok) fsnr += 1; else phase = 5; }
+    }
+};
 
 __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :1513-1524, poly 0x18005
 {
@@ -466,6 +476,10 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
     }
     if (lane < 50) L.hth[lane] = P.tab->hth[lane][P.fscod];
     L.baptab[lane] = P.tab->baptab[lane];
+    {
+        const int bp = P.tab->baptab[lane];
+        L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 10) | ((bp == 2) << 16) | ((bp == 4) << 22) | ((uint32_t)bp << 28);
+    }
     if (lane < 52) { L.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0; L.band_size[lane] = lane < 50 ? P.tab->band_size[lane] : 0; }
 
     // fixed allocation codes (:861-879)
@@ -594,11 +608,22 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             frame_bits += 16;
         }
 
-        // ---- per-lane view of the coefficient stream: lane owns items [t0, t1) of every block ----
-        const int R = (T + 63) >> 6;
-        const int t0 = lane * R < T ? lane * R : T, t1 = (lane + 1) * R < T ? (lane + 1) * R : T;
-        int ch0 = t0 / nbc, bin0 = t0 - ch0 * nbc;
-        if (ch0 >= nfbw) { ch0 = nfbw; bin0 = t0 - nfbw * nbc; }
+        // ---- per-lane view of the coefficient stream: item k of a lane is coefficient 64k + lane of every
+        //      block's mantissa stream (channel-major, LFE last).  desc = E-row offset | mask index << 16 ----
+        int desc[RT];
+        uint32_t vmask = 0;
+#pragma unroll
+        for (int k = 0; k < RT; k++) {
+            const int t = 64 * k + lane;
+            int ch = t / nbc;
+            ch = ch < nfbw ? ch : nfbw;
+            int bin = t - ch * nbc;
+            const bool valid = t < T;
+            bin = valid ? bin : 0;
+            ch = valid ? ch : 0;
+            desc[k] = (ch * 256 + bin) | ((ch * 50 + L.band_of_bin[bin]) << 16);
+            vmask |= (valid ? 1u : 0u) << k;
+        }
         if (lane < 36) {
             const int b = lane / 6, ch = lane - 6 * b;
             L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
@@ -607,46 +632,57 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         for (int i = lane; i < 36 * 50; i += 64) (&L.mask[0][0])[i] -= (int16_t)floorv;
         WAVE_SYNC();
 
-        // ---- SNR offset search, exactly the reference's sequence (:921-967), one evaluation site ----
+        // ---- SNR offset search, exactly the reference's sequence (:921-967).  Up to three candidates are
+        //      evaluated per sweep over the coefficients, chosen by running the reference's loop ahead on
+        //      the assumption that each one fits; the verdicts are then consumed in the reference's order
+        //      and everything after the first surprise is discarded. ----
         const int budget = 16 * fs - frame_bits;
-        int csnr = csnr_prev, fsnr = 0, phase = 0;
-        bool failed = false;
-        while (phase < 5) {
-            int cc = csnr, ff = fsnr;
-            if (phase == 0) { if (csnr < 0) { failed = true; break; } }
-            else if (phase == 1) { if (csnr + 4 > 63) { phase = 2; continue; } cc = csnr + 4; }
-            else if (phase == 2) { if (csnr + 1 > 63) { phase = 3; continue; } cc = csnr + 1; }
-            else if (phase == 3) { if (fsnr + 4 > 15) { phase = 4; continue; } ff = fsnr + 4; }
-            else { if (fsnr + 1 > 15) break; ff = fsnr + 1; }
-            const int so = (((cc - 15) << 4) + ff) << 2;
-            // mantissa bits of the whole frame at this offset (:764-845)
-            int total = 0;
+        SnrSearch ss{csnr_prev, 0, 0, false};
+        for (;;) {
+            int so[3], n_cand = 0;
+            {
+                SnrSearch ahead = ss;
+                int cc, ff;
+                while (n_cand < 3 && ahead.next(cc, ff)) {
+                    const int v = (((cc - 15) << 4) + ff) << 2;
+                    if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                    so[n_cand++] = v;
+                    ahead.consume(true);
+                }
+            }
+            if (n_cand == 0) break;
+            int total[3] = {0, 0, 0};
 #pragma unroll 1
             for (int b = 0; b < 6; b++) {
-                int cnt = 0, bits = 0, ch = ch0, bin = bin0;
-                // uniform trip count (R is wave-uniform) so that the compiler can batch the LDS reads of 6 items
-#pragma unroll 6
-                for (int k = 0; k < R; k++) {
-                    const int r = b * 6 + ch;
-                    int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], so);
-                    bp = (t0 + k < t1) ? bp : 0;
-                    cnt += bp == 1 ? 1 : bp == 2 ? (1 << 11) : bp == 4 ? (1 << 22) : 0;
-                    bits += plain_bits(bp);
-                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
+                uint32_t acc[3] = {0, 0, 0};
+                const uint8_t *Eb = &L.E[b * 6][0];
+                const int16_t *Mb = &L.mask[b * 6][0];
+#pragma unroll
+                for (int k = 0; k < RT; k++) {
+                    if (64 * k >= T) continue;                              // wave-uniform
+                    const int e = Eb[desc[k] & 0xffff], m = Mb[desc[k] >> 16];
+                    const int d4 = ((vmask >> k) & 1) ? 320 - 16 * e : -(1 << 20);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[c] += L.bitlut[lut_index(d4, m, so[c])];
                 }
-                cnt = wave_sum(cnt);
-                bits = wave_sum(bits);
-                const int n1 = cnt & 0x7ff, n2 = (cnt >> 11) & 0x7ff, n4 = (cnt >> 22) & 0x3ff;
-                total += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t sa = wave_sum_u32((acc[c] & 0x3ffu) | (((acc[c] >> 10) & 63u) << 16));
+                    const uint32_t sb = wave_sum_u32(((acc[c] >> 16) & 63u) | (((acc[c] >> 22) & 63u) << 16));
+                    const int bits = sa & 0xffff, n1 = sa >> 16, n2 = sb & 0xffff, n4 = sb >> 16;
+                    total[c] += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+                }
             }
-            const bool ok = budget - total >= 0;
-            if (phase == 0) { if (ok) phase = 1; else csnr -= 4; }
-            else if (phase == 1) { if (ok) csnr += 4; else phase = 2; }
-            else if (phase == 2) { if (ok) csnr += 1; else phase = 3; }
-            else if (phase == 3) { if (ok) fsnr += 4; else phase = 4; }
-            else { if (ok) fsnr += 1; else break; }
+            for (int i = 0; i < n_cand; i++) {
+                int cc, ff;
+                ss.next(cc, ff);
+                const bool ok = budget - total[i] >= 0;
+                ss.consume(ok);
+                if (!ok) break;
+            }
         }
-        if (!failed) csnr_prev = csnr;
+        int csnr = ss.csnr, fsnr = ss.fsnr;
+        if (!ss.failed) csnr_prev = csnr;
         else { csnr = 0; fsnr = 0; }        // reference: error path, out of contract for every supported bit rate
         const int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
         if (P.tap_snr && lane == 0) { P.tap_snr[fidx * 2] = csnr; P.tap_snr[fidx * 2 + 1] = fsnr; }
@@ -705,89 +741,82 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             put(1, 0);
             put(1, 0);
 
-            // ---- mantissas ----
-            // All item loops run the wave-uniform trip count R with a validity predicate, so they can be
-            // unrolled and their LDS / HBM reads batched.
-            // pass 1: bap of every coefficient of this block, group ranks
-            int n3 = 0, n5 = 0, n11 = 0;
-            {
-                int ch = ch0, bin = bin0;
-#pragma unroll 6
-                for (int k = 0; k < R; k++) {
-                    const int r = b * 6 + ch;
-                    int bp = item_bap(L.mask[r][L.band_of_bin[bin]], L.E[r][bin], snroffset);
-                    if (t0 + k < t1) {
-                        L.bapb[ch][bin] = (uint8_t)bp;
-                        n3 += bp == 1; n5 += bp == 2; n11 += bp == 4;
-                    }
-                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
-                }
-            }
-            for (int i = lane; i < GTOT; i += 64) L.gtab[i] = 0;
-            int tot3, tot5, tot11, totbits;
-            const int r3 = wave_excl_scan(n3, lane, &tot3), r5 = wave_excl_scan(n5, lane, &tot5);
-            const int r11 = wave_excl_scan(n11, lane, &tot11);
-            // pass 2: widths
-            int nbits = 0;
-            {
-                int c3 = r3, c5 = r5, c11 = r11, ch = ch0, bin = bin0;
-#pragma unroll 6
-                for (int k = 0; k < R; k++) {
-                    const int bp = (t0 + k < t1) ? L.bapb[ch][bin] : 0;
-                    nbits += bp == 1 ? (c3 % 3 == 0 ? 5 : 0) : bp == 2 ? (c5 % 3 == 0 ? 7 : 0) : bp == 4 ? ((c11 & 1) == 0 ? 7 : 0)
-                                     : plain_bits(bp);
-                    c3 += bp == 1; c5 += bp == 2; c11 += bp == 4;
-                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
-                }
-            }
-            uint32_t off = pos + (uint32_t)wave_excl_scan(nbits, lane, &totbits);
-            WAVE_SYNC();
-            // pass 3: quantise; plain mantissas go straight into the frame, grouped ones are summed per group
-            {
-                int c3 = r3, c5 = r5, c11 = r11, ch = ch0, bin = bin0;
-                const int32_t *mdb = md + (size_t)b * nch * 256;
-#pragma unroll 6
-                for (int k = 0; k < R; k++) {
-                    const bool valid = t0 + k < t1;
-                    const int bp = valid ? L.bapb[ch][bin] : 0;
-                    const int c = bp ? mdb[ch * 256 + bin] : 0;
-                    const int e = (int)L.E[b * 6 + ch][bin] - (int)L.shiftv[b * 6 + ch];
-                    if (bp == 1 || bp == 2 || bp == 4) {
-                        // grouped 3-, 5-, 11-level codes: member m of group g adds weight * value, the first one also the offset
-                        const int levels = bp == 1 ? 3 : bp == 2 ? 5 : 11;
-                        const int per = bp == 4 ? 2 : 3, bits_g = bp == 1 ? 5 : 7;
-                        const int rank = bp == 1 ? c3 : bp == 2 ? c5 : c11;
-                        const int m = rank % per, g = rank / per;
-                        const int v = quant_sym(c, e, levels);
-                        const int w0 = bp == 4 ? levels : levels * levels;              // 9, 25, 11
-                        uint32_t add = (uint32_t)(v * (m == 0 ? w0 : (m == 1 && per == 3) ? levels : 1));
-                        if (m == 0) { add |= (off - pos) << 8; off += bits_g; }
-                        atomicAdd(&L.gtab[(bp == 1 ? G3 : bp == 2 ? G5 : G11) + g], add);
-                        c3 += bp == 1; c5 += bp == 2; c11 += bp == 4;
-                    } else if (bp) {
-                        const int w = plain_bits(bp);
-                        const int v = bp == 3 ? quant_sym(c, e, 7) : bp == 5 ? quant_sym(c, e, 15) : quant_asym(c, e, w);
-                        put_bits(L.fr, off, w, (uint32_t)v);
-                        off += w;
-                    }
-                    if (++bin == nbc && ch < nfbw) { bin = 0; ch++; }
-                }
-            }
-            WAVE_SYNC();
-            // pass 4: grouped codes
-            for (int g = lane; g < (tot3 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G3 + g]; put_bits(L.fr, pos + (x >> 8), 5, x & 0xff); }
-            for (int g = lane; g < (tot5 + 2) / 3; g += 64) { const uint32_t x = L.gtab[G5 + g]; put_bits(L.fr, pos + (x >> 8), 7, x & 0xff); }
-            for (int g = lane; g < (tot11 + 1) / 2; g += 64) { const uint32_t x = L.gtab[G11 + g]; put_bits(L.fr, pos + (x >> 8), 7, x & 0xff); }
-            pos += (uint32_t)totbits;
+            // ---- mantissas (:1334-1502): one sweep, 64 consecutive coefficients per step.  Two packed
+            //      wavefront scans per step give every coefficient its rank among the 3/5/11-level codes
+            //      and its bit offset.  A grouped code is assembled in L.gtab (ring of 128 slots per kind,
+            //      only the newest group of a kind can be incomplete): the opener stores offset and its
+            //      weighted value, later members add theirs, the last member writes the code out. ----
             if (P.tap_bap) {
                 uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
                 uint8_t *te = P.tap_eexp + (fidx * 6 + b) * nch * 256;
                 for (int ch = 0; ch < nch; ch++)
                     for (int i = lane; i < 256; i += 64) {
                         const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-                        tb[ch * 256 + i] = i < n ? L.bapb[ch][i] : 0;
+                        if (i >= n) tb[ch * 256 + i] = 0;
                         te[ch * 256 + i] = L.E[b * 6 + ch][i];
                     }
+            }
+            {
+                const uint8_t *Eb = &L.E[b * 6][0];
+                const int16_t *Mb = &L.mask[b * 6][0];
+                const int32_t *mdb = md + (size_t)b * nch * 256;
+                int b3 = 0, b5 = 0, b11 = 0;
+#pragma unroll
+                for (int k = 0; k < RT; k++) {
+                    if (64 * k >= T) continue;                              // wave-uniform
+                    const int eo = desc[k] & 0xffff;
+                    const bool valid = (vmask >> k) & 1;
+                    const int ex = Eb[eo], m = Mb[desc[k] >> 16];
+                    const int d4 = valid ? 320 - 16 * ex : -(1 << 20);
+                    const uint32_t lut = L.bitlut[lut_index(d4, m, snroffset)];
+                    const int bp = (int)(lut >> 28);
+                    const int c = mdb[eo];
+                    const int e = ex - (int)L.shiftv[b * 6 + (eo >> 8)];
+                    if (P.tap_bap && valid) P.tap_bap[(fidx * 6 + b) * nch * 256 + eo] = (uint8_t)bp;
+
+                    const int kind = bp == 1 ? 0 : bp == 2 ? 1 : bp == 4 ? 2 : -1;
+                    const uint32_t gcnt = kind < 0 ? 0u : 1u << (8 * kind);
+                    const uint32_t gincl = wave_incl_scan_u32(gcnt);
+                    const uint32_t gexcl = gincl - gcnt;
+                    const int rank = kind == 0 ? b3 + (int)(gexcl & 255u)
+                                   : kind == 1 ? b5 + (int)((gexcl >> 8) & 255u)
+                                               : b11 + (int)(gexcl >> 16);
+                    const int grp = kind == 2 ? rank >> 1 : (int)(((uint32_t)rank * 0xaaabu) >> 17);   // rank / 3, rank < 2^15
+                    const int per = kind == 2 ? 2 : 3;
+                    const int mem = rank - grp * per;
+                    const bool grouped = kind >= 0;
+                    const bool opens = grouped && mem == 0;
+                    const int gbits = kind == 0 ? 5 : 7;
+                    const int w = (int)(lut & 0x3ffu);
+                    const int nb = grouped ? (opens ? gbits : 0) : w;
+                    const uint32_t bincl = wave_incl_scan_u32((uint32_t)nb);
+                    const uint32_t off = pos + bincl - (uint32_t)nb;
+                    const uint32_t gtot = wave_last(gincl);
+
+                    // quantise (:1150-1190)
+                    const int levels = bp == 1 ? 3 : bp == 2 ? 5 : bp == 4 ? 11 : bp == 3 ? 7 : 15;
+                    const bool sym = grouped || bp == 3 || bp == 5;
+                    const int v = sym ? quant_sym(c, e, levels) : quant_asym(c, e, w ? w : 1);
+                    if (!grouped) put_bits(L.fr, off, w, (uint32_t)v);
+
+                    uint32_t *slot = &L.gtab[kind < 0 ? 0 : kind][grp & 127];
+                    const int wgt = mem == per - 1 ? 1 : mem == 0 ? (kind == 2 ? 11 : levels * levels) : levels;
+                    if (opens) *slot = (off << 8) | (uint32_t)(v * wgt);
+                    WAVE_SYNC();
+                    if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt));
+                    WAVE_SYNC();
+                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(L.fr, x >> 8, gbits, x & 0xff); }
+
+                    b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
+                    pos += wave_last(bincl);
+                }
+                // a trailing group that never got its last member is written as it stands
+                WAVE_SYNC();
+                if (lane == 0) {
+                    if (b3 % 3) { const uint32_t x = L.gtab[0][(b3 / 3) & 127]; put_bits(L.fr, x >> 8, 5, x & 0xff); }
+                    if (b5 % 3) { const uint32_t x = L.gtab[1][(b5 / 3) & 127]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
+                    if (b11 & 1) { const uint32_t x = L.gtab[2][(b11 >> 1) & 127]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
+                }
             }
             WAVE_SYNC();
         }
