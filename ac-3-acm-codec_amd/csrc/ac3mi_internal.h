@@ -95,6 +95,10 @@ struct EncodeLaunch {
     int32_t *ws_mdct;           // [S][F][6][nch][256]
     uint8_t *ws_expo;           // [S][F][6][nch][256]
     int8_t *ws_shift;           // [S][F][6][nch]
+    uint8_t *ws_eexp;           // [S][F][6][nch][256] encoded exponents
+    int16_t *ws_emask;          // [S][F][6][nch][50]  masking curves minus the floor
+    uint8_t *ws_strat;          // [S][F][6][nch]
+    int32_t *ws_ebits;          // [S][F][nch]
     uint8_t *tap_eexp, *tap_bap, *tap_strat;
     int32_t *tap_snr;
 };

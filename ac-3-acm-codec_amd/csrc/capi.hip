@@ -664,7 +664,12 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
         }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t rows = (size_t)n_streams * frames_per_stream * 6 * E.cfg.nch;
-    const size_t need = rows * 256 * 4 + rows * 256 + ((rows + 255) & ~(size_t)255) + 1024;
+    const size_t rows_pad = (rows + 255) & ~(size_t)255;
+    // mdct | raw exponents | encoded exponents | masking curves | exp_samples | strategies | exponent bits
+    const size_t off_expo = rows * 256 * 4, off_eexp = off_expo + rows * 256, off_emask = off_eexp + rows * 256;
+    const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
+    const size_t off_ebits = off_strat + rows_pad;
+    const size_t need = off_ebits + rows_pad * 4 + 1024;
     if (need > ctx->ws_enc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_enc);
@@ -674,8 +679,12 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
         ctx->ws_enc_bytes = need;
     }
     E.ws_mdct = (int32_t *)ctx->ws_enc;
-    E.ws_expo = (uint8_t *)ctx->ws_enc + rows * 256 * 4;
-    E.ws_shift = (int8_t *)ctx->ws_enc + rows * 256 * 4 + rows * 256;
+    E.ws_expo = (uint8_t *)ctx->ws_enc + off_expo;
+    E.ws_eexp = (uint8_t *)ctx->ws_enc + off_eexp;
+    E.ws_emask = (int16_t *)((uint8_t *)ctx->ws_enc + off_emask);
+    E.ws_shift = (int8_t *)ctx->ws_enc + off_shift;
+    E.ws_strat = (uint8_t *)ctx->ws_enc + off_strat;
+    E.ws_ebits = (int32_t *)((uint8_t *)ctx->ws_enc + off_ebits);
     if (taps && taps->d_mdct) E.ws_mdct = taps->d_mdct;
     if (taps && taps->d_exponent) E.ws_expo = taps->d_exponent;
     if (taps && taps->d_exp_samples) E.ws_shift = taps->d_exp_samples;

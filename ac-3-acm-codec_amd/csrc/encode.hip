@@ -201,7 +201,10 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
 
 struct PackParams {
     const int32_t *mdct;
-    const uint8_t *expo;
+    const uint8_t *eexp;        // [S][F][6][nch][256] encoded exponents   (enc_exp_kernel)
+    const int16_t *emask;       // [S][F][6][nch][50]  masking curve minus the floor
+    const uint8_t *strat;       // [S][F][6][nch]
+    const int32_t *ebits;       // [S][F][nch] bits of the coded exponents
     const int8_t *shift;
     int32_t *csnr_state;        // [S] in/out
     uint8_t *frames;            // [S][F][stride]
@@ -224,21 +227,23 @@ constexpr int PK_MAXBYTES = 3840 + 256;
 constexpr int PK_FRW = PK_MAXBYTES / 4;
 
 
+// tables of the PSD / masking-curve computation
+struct MaskTabs {
+    uint8_t latab[256];
+    uint16_t hth[50];
+    uint8_t band_of_bin[256];
+    uint8_t band_start[52];
+};
+
 struct PackLDS {
-    uint8_t E[36][256];         // exponents, raw then encoded in place   [blk*6+ch]
-    int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor once the search starts
+    uint8_t E[36][256];         // encoded exponents   [blk*6+ch]
+    int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
     uint32_t gtab[3][128];      // 3/5/11-level codes being assembled: code (bits 0..6) | bit offset << 8
     uint32_t bitlut[64];        // see lut_index
     uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
     int8_t shiftv[36];          // exp_samples of the frame
-    int diff[6][6];
     uint8_t strat[6][6];
-    uint8_t latab[256];
-    uint16_t hth[50];
-    uint8_t baptab[64];
     uint8_t band_of_bin[256];
-    uint8_t band_start[52];
-    uint8_t band_size[52];
     uint16_t crc_tab[256];
 };
 
@@ -270,23 +275,39 @@ __device__ __forceinline__ int lowcomp_step(int a, int b0, int b1, int bin)     
 // PSD integration, excitation and mask for one (block, channel) - run by ONE lane, in place in its LDS row:
 // first the band PSDs are written to mask[], then one forward walk turns them into the masking curve
 // (band b only needs bndpsd[b] and bndpsd[b+1], both still intact when b is overwritten).   :220-367
-__device__ void compute_mask_lane(PackLDS &L, const uint8_t *exp, int end, bool is_lfe, int16_t *mask,
+__device__ void compute_mask_lane(const MaskTabs &L, const uint8_t *exp, int end, bool is_lfe, int16_t *mask,
                                   int sdecay, int fdecay, int sgain, int dbknee, int fgain, int halfrate)
 {
     int j = 0, k = 0, v, lowcomp = 0, fast = 0, slow = 0, begin, end1, bin;
-    do {
+    auto logadd = [&](int a, int pj) {
+        const int c = a - pj;
+        int t = (c >= 0 ? c : -c) >> 1;
+        t = t > 255 ? 255 : t;
+        return (c >= 0 ? a : pj) + (int)L.latab[t];
+    };
+    // bands 0..27 are one bin wide
+    const int nsingle = end < 28 ? end : 28;
+#pragma unroll 4
+    for (; k < nsingle; k++) mask[k] = (int16_t)(3072 - ((int)(int8_t)exp[k] << 7));
+    j = k;
+    // wider bands (3, 6, 12, 24 bins): three exponents per step, so their LDS reads are independent
+    while (j < end) {
+        end1 = L.band_start[k + 1] < end ? L.band_start[k + 1] : end;
         v = 3072 - ((int)(int8_t)exp[j] << 7);
         j++;
-        end1 = L.band_start[k + 1] < end ? L.band_start[k + 1] : end;
-        for (; j < end1; j++) {
-            const int pj = 3072 - ((int)(int8_t)exp[j] << 7);
-            const int c = v - pj;
-            int a;
-            if (c >= 0) { a = c >> 1; if (a > 255) a = 255; v = v + L.latab[a]; }
-            else { a = (-c) >> 1; if (a > 255) a = 255; v = pj + L.latab[a]; }
+        if (j + 2 <= end1) {
+            const int p1 = 3072 - ((int)(int8_t)exp[j] << 7), p2 = 3072 - ((int)(int8_t)exp[j + 1] << 7);
+            v = logadd(logadd(v, p1), p2);
+            j += 2;
         }
+        for (; j + 3 <= end1; j += 3) {
+            const int p0 = 3072 - ((int)(int8_t)exp[j] << 7), p1 = 3072 - ((int)(int8_t)exp[j + 1] << 7);
+            const int p2 = 3072 - ((int)(int8_t)exp[j + 2] << 7);
+            v = logadd(logadd(logadd(v, p0), p1), p2);
+        }
+        for (; j < end1; j++) v = logadd(v, 3072 - ((int)(int8_t)exp[j] << 7));
         mask[k++] = (int16_t)v;
-    } while (end > L.band_start[k]);
+    }
 
     const int bndend = L.band_of_bin[end - 1] + 1;
     auto finish = [&](int b, int excite, int psd) {                  // masking curve :357-367
@@ -336,26 +357,304 @@ __device__ void compute_mask_lane(PackLDS &L, const uint8_t *exp, int end, bool 
 
 // constrain_exponents = encode_exp (:684-761), in place on one 256-byte row, run by ONE lane.
 // (nb_groups counts exponent entries after grouping: up to 222 for D15.)
+// The +-2 delta constraint has the closed form min over j of g[j] + 2|i-j|: one ascending sweep (fused with
+// the group minima) and one descending sweep (fused with the expansion back to bins).  Both sweeps carry
+// the neighbour in a register and move 8 entries per step, so the LDS reads of a step are independent.
 __device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
 {
     const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
     const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
-    // group minima, compacted to row[1..ng] (reads run ahead of writes: k >= i)
-    for (int i = 1, k = 1; i <= ng; i++, k += gs) {
-        int m = row[k];
-        for (int j = 1; j < gs; j++) if (row[k + j] < m) m = row[k + j];
-        row[i] = (uint8_t)m;
+    int prev = row[0] > 15 ? 15 : row[0];
+    row[0] = (uint8_t)prev;
+    // ascending: entry i = min of bins 1+(i-1)gs .. +gs-1, then <= previous entry + 2.  Reads run ahead of
+    // writes (bin index >= entry index).
+    for (int i0 = 1; i0 <= ng; i0 += 8) {
+        int m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u < ng ? i0 + u : ng;
+            const int k = 1 + (i - 1) * gs;
+            int x = row[k];
+            if (gs >= 2) { const int y = row[k + 1]; x = y < x ? y : x; }
+            if (gs == 4) { const int y = row[k + 2], z = row[k + 3]; x = y < x ? y : x; x = z < x ? z : x; }
+            m[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i0 + u > ng) break;
+            prev = m[u] < prev + 2 ? m[u] : prev + 2;
+            row[i0 + u] = (uint8_t)prev;
+        }
     }
-    if (row[0] > 15) row[0] = 15;
-    // fixed point of the +-2 delta constraint = min_j g[j] + 2|i-j|: forward then backward sweep
-    for (int i = 1; i <= ng; i++) if (row[i] > row[i - 1] + 2) row[i] = (uint8_t)(row[i - 1] + 2);
-    for (int i = ng - 1; i >= 0; i--) if (row[i] > row[i + 1] + 2) row[i] = (uint8_t)(row[i + 1] + 2);
-    // expand back to bins, last group first (writes stay at or above the group index)
-    for (int i = ng, k = 1 + (ng - 1) * gs; i >= 1; i--, k -= gs) {
-        const uint8_t v = row[i];
-        for (int j = gs - 1; j >= 0; j--) row[k + j] = v;
+    // descending: entry i <= next entry + 2, then copied to its gs bins (writes stay at or above the entry
+    // index, and above every entry a later step still has to read)
+    int next = row[ng];
+    for (int i0 = ng; i0 >= 1; i0 -= 8) {
+        int m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) m[u] = row[i0 - u >= 1 ? i0 - u : 1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 - u;
+            if (i < 1) break;
+            if (i < ng) next = m[u] < next + 2 ? m[u] : next + 2;
+            const int k = 1 + (i - 1) * gs;
+            row[k] = (uint8_t)next;
+            if (gs >= 2) row[k + 1] = (uint8_t)next;
+            if (gs == 4) { row[k + 2] = (uint8_t)next; row[k + 3] = (uint8_t)next; }
+        }
     }
+    if (row[0] > next + 2 && ng >= 1) row[0] = (uint8_t)(row[1] + 2);
     return 4 + (ng / 3) * 7;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront-wide versions of the two routines above for enc_exp_kernel (same results).
+
+// encode_exp on one row: entry i = 1 + 64c + lane of chunk c.  min over j of g[j] + 2|i-j| is a prefix minimum of
+// g[j] - 2j (ascending) followed by a suffix minimum of g[j] + 2j (descending).
+__device__ int encode_exp_wave(uint8_t *row, int n, int strategy, int lane)
+{
+    constexpr int INF = 0x3fffffff;
+    const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
+    const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
+    int row0 = row[0];
+    row0 = row0 > 15 ? 15 : row0;
+    int g[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int i = 1 + 64 * c + lane;
+        const int k = 1 + (i - 1) * gs;
+        int x = INF;
+        if (i <= ng) {
+            x = row[k];
+            if (gs >= 2) { const int y = row[k + 1]; x = y < x ? y : x; }
+            if (gs == 4) { const int y = row[k + 2], z = row[k + 3]; x = y < x ? y : x; x = z < x ? z : x; }
+        }
+        g[c] = x;
+    }
+    int carry = row0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (64 * c >= ng) continue;
+        const int i = 1 + 64 * c + lane;
+        int s = wave_incl_scan_min(i <= ng ? g[c] - 2 * i : INF);
+        s = s < carry ? s : carry;
+        carry = __builtin_amdgcn_readlane(s, 63);
+        g[c] = i <= ng ? s + 2 * i : INF;
+    }
+    carry = INF;
+#pragma unroll
+    for (int c = 3; c >= 0; c--) {
+        if (64 * c >= ng) continue;
+        const int i = 1 + 64 * c + lane;
+        int s = wave_suffix_scan_min(i <= ng ? g[c] + 2 * i : INF, lane);
+        s = s < carry ? s : carry;
+        carry = __builtin_amdgcn_readlane(s, 0);
+        g[c] = s - 2 * i;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int i = 1 + 64 * c + lane;
+        const int k = 1 + (i - 1) * gs;
+        if (i <= ng) {
+            row[k] = (uint8_t)g[c];
+            if (gs >= 2) row[k + 1] = (uint8_t)g[c];
+            if (gs == 4) { row[k + 2] = (uint8_t)g[c]; row[k + 3] = (uint8_t)g[c]; }
+        }
+    }
+    if (lane == 0) row[0] = (uint8_t)(carry < row0 ? carry : row0);
+    return 4 + (ng / 3) * 7;
+}
+
+// Masking curve of one row, one lane per band (:220-367).  bndpsd[] must hold the band PSDs.
+//  * lowcomp is a reset-or-decrement automaton: value = max(0, R(last reset) - 64 * decrements since)
+//  * the fast / slow leaks are prefix maxima of psd - gain + band * decay, seeded at band begin-1
+__device__ void mask_row_wave(const MaskTabs &T, int16_t *bndpsd, int bndend, bool is_lfe, int sdecay, int fdecay, int sgain,
+                              int dbknee, int fgain, int halfrate, int lane)
+{
+    constexpr int NEG = -0x3fffffff;
+    const int b = lane;
+    const int cur = b < bndend ? bndpsd[b] : 0;
+    const int nxt = (b + 1 < bndend && !(is_lfe && b == 6)) ? bndpsd[b + 1] : 0;
+    const bool skip = (is_lfe && b == 6) || b >= 22 || b >= bndend;
+    const bool reset = !skip && b < 20 && cur + 256 == nxt;
+    const int dec = skip || reset ? 0 : b >= 20 ? 2 : (cur > nxt ? 1 : 0);
+    const int D = (int)wave_incl_scan_u32((uint32_t)dec);
+    const int rix = wave_incl_scan_max(reset ? b : NEG);
+    const int Dr = __shfl(D, rix < 0 ? 0 : rix, 64);
+    int lowcomp = 0;
+    if (rix >= 0) { lowcomp = (rix < 7 ? 384 : 320) - 64 * (D - Dr); lowcomp = lowcomp < 0 ? 0 : lowcomp; }
+
+    const bool stop = b >= 2 && b < 7 && b < bndend && !(is_lfe && b == 6) && cur <= nxt;
+    const unsigned long long sm = __ballot(stop);
+    const int begin = sm ? __builtin_ctzll(sm) + 1 : 7;
+    const bool live = b >= begin - 1 && b < bndend;
+    const int fast = wave_incl_scan_max(live ? cur - fgain + b * fdecay : NEG) - b * fdecay;
+    const int slow = wave_incl_scan_max(live ? cur - sgain + b * sdecay : NEG) - b * sdecay;
+    int excite;
+    if (b < begin) excite = (int16_t)(cur - fgain - lowcomp);
+    else if (b < 22) { const int v = fast - lowcomp; excite = (int16_t)(slow > v ? slow : v); }
+    else excite = (int16_t)(fast > slow ? fast : slow);
+    const int t = dbknee - cur;
+    if (t > 0) excite += t >> 2;
+    const int h = T.hth[(b < 50 ? b : 49) >> halfrate];
+    if (b < 50) bndpsd[b] = b < bndend ? (int16_t)(excite > h ? excite : h) : (int16_t)0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 1b: exponent strategy, min-merge, constraint and masking curves.  Everything here is
+// independent per channel, so one wavefront takes the six blocks of one (stream, frame, channel).
+
+struct ExpParams {
+    const uint8_t *expo;        // [S][F][6][nch][256] raw exponents (enc_mdct_kernel)
+    uint8_t *eexp;              // same shape, encoded
+    int16_t *emask;             // [S][F][6][nch][50]
+    uint8_t *strat;             // [S][F][6][nch]
+    int32_t *ebits;             // [S][F][nch]
+    const EncTables *tab;
+    int nch, lfe, fscod, halfrate, nbc;
+};
+
+struct ExpLDS {
+    uint8_t E[6][256];
+    int16_t mask[6][50];
+    MaskTabs t;
+    uint8_t strat[8];
+};
+
+__global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
+{
+    __shared__ ExpLDS L;
+    const int lane = threadIdx.x;
+    const int nch = P.nch;
+    const size_t fidx = blockIdx.x / nch;
+    const int ch = blockIdx.x - (int)fidx * nch;
+    const bool is_lfe = P.lfe && ch == nch - 1;
+    const int n = is_lfe ? 7 : P.nbc;
+
+    for (int i = lane; i < 256; i += 64) {
+        L.t.latab[i] = P.tab->latab[i];
+        L.t.band_of_bin[i] = P.tab->band_of_bin[i];
+    }
+    if (lane < 50) L.t.hth[lane] = P.tab->hth[lane][P.fscod];
+    if (lane < 52) L.t.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0;
+
+    // ---- raw exponents, four bins per lane ----
+    uint32_t raw[6];
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        raw[b] = *reinterpret_cast<const uint32_t *>(P.expo + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane);
+        *reinterpret_cast<uint32_t *>(&L.E[b][4 * lane]) = raw[b];
+    }
+
+    // ---- exponent strategy (:617-669): sum of |differences| over all 256 bins against the block before ----
+    int st[6];
+    st[0] = 1;
+#pragma unroll
+    for (int b = 1; b < 6; b++) st[b] = wave_sum((int)__builtin_amdgcn_sad_u8(raw[b], raw[b - 1], 0u)) > 1000 ? 1 : 0;
+    if (!is_lfe) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            if (st[b] == 0) continue;
+            int run = 1;                                                // blocks until the next new set
+#pragma unroll
+            for (int e = 1; e < 6; e++) if (b + e < 6 && run == e && st[b + e] == 0) run = e + 1;
+            st[b] = run == 1 ? 3 : run <= 3 ? 2 : 1;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) L.strat[b] = (uint8_t)st[b];
+    }
+    WAVE_SYNC();
+
+    // ---- min-merge over reuse runs (:1731-1737), lanes over bins ----
+    {
+        int b = 0;
+        while (b < 6) {
+            int e = b + 1;
+            while (e < 6 && L.strat[e] == 0) {
+                for (int j = lane; j < n; j += 64) {
+                    const uint8_t x = L.E[e][j];
+                    if (x < L.E[b][j]) L.E[b][j] = x;
+                }
+                e++;
+            }
+            b = e;
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- encode_exp on run starts, then replicate (:1739-1746) ----
+    int exp_bits = 0;
+    for (int b = 0; b < 6; b++) {
+        const int stg = L.strat[b];
+        if (stg != 0) exp_bits += encode_exp_wave(L.E[b], n, stg, lane);
+    }
+    WAVE_SYNC();
+    {
+        int src = 0;
+        for (int b = 1; b < 6; b++) {
+            if (L.strat[b] != 0) { src = b; continue; }
+            for (int j = lane; j < n; j += 64) L.E[b][j] = L.E[src][j];
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- band PSDs (:220-258): bands 0..27 are single bins; the 22 wider ones are integrated by one
+    //      lane each, two rows per sweep ----
+    {
+        const int nsingle = n < 28 ? n : 28;
+        for (int b = 0; b < 6; b++)
+            if (lane < nsingle) L.mask[b][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[b][lane] << 7));
+        if (n > 28) {
+            for (int p = 0; p < 3; p++) {
+                const int r = 2 * p + (lane >> 5), band = 28 + (lane & 31);
+                const bool active = (lane & 31) < 22;
+                const int start = L.t.band_start[active ? band : 28];
+                int end1 = L.t.band_start[active ? band + 1 : 29];
+                end1 = end1 < n ? end1 : n;
+                const int wdt = active ? end1 - start : 0;
+                const uint8_t *e = L.E[r];
+                int v = 3072 - ((int)(int8_t)e[start] << 7);
+                for (int j = 1; j < 24; j++) {
+                    const int jj = j < wdt ? start + j : start;
+                    const int pj = 3072 - ((int)(int8_t)e[jj] << 7);
+                    const int c = v - pj;
+                    int t = (c >= 0 ? c : -c) >> 1;
+                    t = t > 255 ? 255 : t;
+                    const int nv = (c >= 0 ? v : pj) + (int)L.t.latab[t];
+                    v = j < wdt ? nv : v;
+                }
+                if (wdt > 0) L.mask[r][band] = (int16_t)v;
+            }
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- masking curves (:259-367), fixed allocation codes (:861-879) ----
+    {
+        const int sdecaycod = 2, fdecaycod = 1, fgaincod = 4;
+        const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
+        const int sgain = 0x4d8, dbknee = 0x900, fgain = 128 * (fgaincod + 1);
+        const int bndend = L.t.band_of_bin[n - 1] + 1;
+        for (int b = 0; b < 6; b++)
+            mask_row_wave(L.t, L.mask[b], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
+    }
+    WAVE_SYNC();
+
+    // ---- results: the pack kernel wants the masks minus the floor (0x1f0) ----
+#pragma unroll
+    for (int b = 0; b < 6; b++)
+        *reinterpret_cast<uint32_t *>(P.eexp + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) =
+            *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
+    for (int i = lane; i < 6 * 50; i += 64) {
+        const int b = i / 50, k = i - 50 * b;
+        P.emask[((fidx * 6 + b) * nch + ch) * 50 + k] = (int16_t)(L.mask[b][k] - 0x1f0);
+    }
+    if (lane < 6) P.strat[(fidx * 6 + lane) * nch + ch] = L.strat[lane];
+    if (lane == 0) P.ebits[fidx * nch + ch] = exp_bits;
 }
 
 // bap of one coefficient for SNR offset `snroffset` (:393-420):
@@ -470,22 +769,16 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
     if (s >= P.n_streams) return;
 
     for (int i = lane; i < 256; i += 64) {
-        L.latab[i] = P.tab->latab[i];
         L.band_of_bin[i] = P.tab->band_of_bin[i];
         L.crc_tab[i] = P.tab->crc_tab[i];
     }
-    if (lane < 50) L.hth[lane] = P.tab->hth[lane][P.fscod];
-    L.baptab[lane] = P.tab->baptab[lane];
     {
         const int bp = P.tab->baptab[lane];
         L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 10) | ((bp == 2) << 16) | ((bp == 4) << 22) | ((uint32_t)bp << 28);
     }
-    if (lane < 52) { L.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0; L.band_size[lane] = lane < 50 ? P.tab->band_size[lane] : 0; }
 
     // fixed allocation codes (:861-879)
     const int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
-    const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
-    const int sgain = 0x4d8, dbknee = 0x900, floorv = 0x1f0, fgain = 128 * (fgaincod + 1);
     const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
     const int T = nfbw * nbc + (P.lfe ? 7 : 0);
     const int fs = P.frame_words;
@@ -494,99 +787,27 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
 
     for (int f = 0; f < P.frames_per_stream; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
-        const uint8_t *ex = P.expo + fidx * 6 * nch * 256;
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
-        // ---- raw exponents into LDS ----
+        // ---- encoded exponents, masking curves, strategies and exponent bit counts from enc_exp_kernel ----
+        const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
         for (int r = 0; r < 36; r++) {
             const int b = r / 6, ch = r - 6 * b;
             uint32_t v = 0x18181818u;
             if (ch < nch) v = *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane);
             *reinterpret_cast<uint32_t *>(&L.E[r][4 * lane]) = v;
         }
+        {
+            const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
+            for (int i = lane; i < 6 * nch * 25; i += 64) {
+                const int row = i / 25, w = i - 25 * row, b = row / nch, ch = row - b * nch;
+                reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = gm[i];
+            }
+            if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
+        }
+        int frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
         for (int i = lane; i < PK_FRW; i += 64) L.fr[i] = 0;
-        WAVE_SYNC();
-
-        // ---- exponent strategy (:617-669) ----
-        for (int ch = 0; ch < nch; ch++)
-            for (int b = 1; b < 6; b++) {
-                int d = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int j = lane + 64 * k;
-                    const int x = (int)L.E[b * 6 + ch][j] - (int)L.E[(b - 1) * 6 + ch][j];
-                    d += x < 0 ? -x : x;
-                }
-                d = wave_sum(d);
-                if (lane == 0) L.diff[ch][b] = d;
-            }
-        WAVE_SYNC();
-        if (lane < nch) {
-            const int ch = lane;
-            uint8_t st[6];
-            st[0] = 1;
-            for (int b = 1; b < 6; b++) st[b] = L.diff[ch][b] > 1000 ? 1 : 0;
-            if (!(P.lfe && ch == nch - 1)) {
-                for (int b = 0; b < 6;) {
-                    int e = b + 1;
-                    while (e < 6 && st[e] == 0) e++;
-                    st[b] = (e - b == 1) ? 3 : (e - b <= 3) ? 2 : 1;
-                    b = e;
-                }
-            }
-            for (int b = 0; b < 6; b++) L.strat[b][ch] = st[b];
-        }
-        WAVE_SYNC();
-
-        // ---- min-merge over reuse runs (:1731-1737), lanes over bins ----
-        for (int ch = 0; ch < nch; ch++) {
-            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-            int b = 0;
-            while (b < 6) {
-                int e = b + 1;
-                while (e < 6 && L.strat[e][ch] == 0) {
-                    for (int j = lane; j < n; j += 64) {
-                        const uint8_t x = L.E[e * 6 + ch][j];
-                        if (x < L.E[b * 6 + ch][j]) L.E[b * 6 + ch][j] = x;
-                    }
-                    e++;
-                }
-                b = e;
-            }
-        }
-        WAVE_SYNC();
-
-        // ---- encode_exp on run starts (one lane per (blk, ch)), then replicate (:1739-1746) ----
-        int exp_bits = 0;
-        if (lane < 36) {
-            const int b = lane / 6, ch = lane - 6 * b;
-            if (ch < nch && L.strat[b][ch] != 0) {
-                const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-                exp_bits = encode_exp_lane(L.E[lane], n, L.strat[b][ch]);
-            }
-        }
-        int frame_bits = wave_sum(exp_bits);
-        WAVE_SYNC();
-        for (int ch = 0; ch < nch; ch++) {
-            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-            int src = 0;
-            for (int b = 1; b < 6; b++) {
-                if (L.strat[b][ch] != 0) { src = b; continue; }
-                for (int j = lane; j < n; j += 64) L.E[b * 6 + ch][j] = L.E[src * 6 + ch][j];
-            }
-        }
-        WAVE_SYNC();
-
-        // ---- masks: one lane per (blk, ch) ----
-        if (lane < 36) {
-            const int b = lane / 6, ch = lane - 6 * b;
-            if (ch < nch) {
-                const bool is_lfe = P.lfe && ch == nch - 1;
-                compute_mask_lane(L, L.E[lane], is_lfe ? 7 : nbc, is_lfe, L.mask[lane], sdecay, fdecay, sgain, dbknee,
-                                  fgain, P.halfrate);
-            }
-        }
         WAVE_SYNC();
 
         // ---- fixed side information (:880-916) ----
@@ -628,8 +849,6 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             const int b = lane / 6, ch = lane - 6 * b;
             L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
         }
-        // masks minus floor, so the search loop saves a subtraction
-        for (int i = lane; i < 36 * 50; i += 64) (&L.mask[0][0])[i] -= (int16_t)floorv;
         WAVE_SYNC();
 
         // ---- SNR offset search, exactly the reference's sequence (:921-967).  Up to three candidates are
@@ -891,9 +1110,28 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 
+    ExpParams X;
+    X.expo = E.ws_expo;
+    X.eexp = E.ws_eexp;
+    X.emask = E.ws_emask;
+    X.strat = E.ws_strat;
+    X.ebits = E.ws_ebits;
+    X.tab = tab.enc;
+    X.nch = c.nch;
+    X.lfe = c.lfe;
+    X.fscod = c.fscod;
+    X.halfrate = c.halfrate;
+    X.nbc = 223;
+    hipLaunchKernelGGL(enc_exp_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, X);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
     PackParams P;
     P.mdct = E.ws_mdct;
-    P.expo = E.ws_expo;
+    P.eexp = E.ws_eexp;
+    P.emask = E.ws_emask;
+    P.strat = E.ws_strat;
+    P.ebits = E.ws_ebits;
     P.shift = E.ws_shift;
     P.csnr_state = E.csnr;
     P.frames = E.frames;

@@ -23,4 +23,37 @@ __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__b
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last(wave_incl_scan_u32(v)); }
 
+// prefix minimum / maximum (lanes shifted in from outside a row keep the identity)
+__device__ __forceinline__ int wave_incl_scan_min(int v)
+{
+    constexpr int ID = 0x3fffffff;
+#define AC3MI_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, rows, 0xf, false); v = t < v ? t : v; }
+    AC3MI_STEP(0x111, 0xf) AC3MI_STEP(0x112, 0xf) AC3MI_STEP(0x114, 0xf) AC3MI_STEP(0x118, 0xf)
+    AC3MI_STEP(0x142, 0xa) AC3MI_STEP(0x143, 0xc)
+#undef AC3MI_STEP
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_max(int v)
+{
+    constexpr int ID = -0x3fffffff;
+#define AC3MI_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, rows, 0xf, false); v = t > v ? t : v; }
+    AC3MI_STEP(0x111, 0xf) AC3MI_STEP(0x112, 0xf) AC3MI_STEP(0x114, 0xf) AC3MI_STEP(0x118, 0xf)
+    AC3MI_STEP(0x142, 0xa) AC3MI_STEP(0x143, 0xc)
+#undef AC3MI_STEP
+    return v;
+}
+// suffix minimum: lane i gets min over lanes i..63 (row_shl inside the rows, the row totals through scalars)
+__device__ __forceinline__ int wave_suffix_scan_min(int v, int lane)
+{
+    constexpr int ID = 0x3fffffff;
+#define AC3MI_STEP(ctrl) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, 0xf, 0xf, false); v = t < v ? t : v; }
+    AC3MI_STEP(0x101) AC3MI_STEP(0x102) AC3MI_STEP(0x104) AC3MI_STEP(0x108)
+#undef AC3MI_STEP
+    const int t1 = __builtin_amdgcn_readlane(v, 16), t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
+    const int a2 = t2 < t3 ? t2 : t3, a1 = t1 < a2 ? t1 : a2;
+    const int r = lane >> 4;
+    const int extra = r == 0 ? a1 : r == 1 ? a2 : r == 2 ? t3 : ID;
+    return extra < v ? extra : v;
+}
+
 }  // namespace ac3mi
