@@ -51,6 +51,8 @@ struct DecLDS {
     uint16_t hth[50];
     int8_t width[64];
     uint8_t band_end[30];
+    uint8_t band_of_bin[256];
+    int16_t bmask[52];                    // per-band mask of the channel being allocated
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -269,6 +271,77 @@ __device__ void bit_allocate_lane(const DecLDS &L, BaCtx c, int bndstart, int st
     } while (bin < end);
 }
 
+// The same allocation for one channel with the whole wavefront (one lane per band, then per bin):
+//  * band PSDs: each of the <= 50 bands integrated by its own lane (<= 24 dependent log-adds)
+//  * lowcomp (bands 0..21 of a channel that starts at bin 0) is a reset-or-decrement automaton:
+//    value = max(0, R(last reset) - 64 * decrements since); bands 20/21 take 128 off while > 128
+//  * the fast / slow leaks are prefix minima of psd + gain - band * decay seeded at the last band
+//    of the first loop (bit_allocate.c:150-166), or at the coupling leak values
+__device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int start, int end, const uint8_t *e,
+                                  int8_t *bap, int lane)
+{
+    constexpr int INF = 0x3fffffff, NEG = -0x3fffffff;
+    const int b = lane;
+    // S1: band PSD
+    int lo = b < 21 ? b : (int)L.band_end[b < 50 ? b - 21 : 0];
+    int hi = b < 20 ? b + 1 : (int)L.band_end[b < 50 ? b - 20 : 0];
+    lo = lo > start ? lo : start;
+    hi = hi < end ? hi : end;
+    const int w = b < 50 ? hi - lo : 0;
+    const bool live = w > 0;
+    lo = live ? lo : start;
+    int psd = 128 * e[lo];
+    const int wmax = (int)wave_last((uint32_t)wave_incl_scan_max(w));
+    for (int j = 1; j < wmax; j++) {
+        const int next = 128 * e[j < w ? lo + j : lo];
+        const int d = next - psd, q = d >> 9;
+        int idx = q == -1 ? (-d) >> 1 : d >> 1;
+        idx = idx < 0 ? 0 : idx > 255 ? 255 : idx;
+        const int la = L.la_neg[idx];
+        const int nv = q <= -2 ? next : q == -1 ? next + la : q == 0 ? psd + la : psd;
+        psd = j < w ? nv : psd;
+    }
+    // S2: lowcomp and the extent of the first loop
+    int lc = 0, bA = 0;
+    if (start == 0) {
+        const int eb = e[b < 253 ? b : 0], eb1 = e[b < 252 ? b + 1 : 0], ebm = e[b > 0 && b < 254 ? b - 1 : 0];
+        const bool upd = b < 20 && (b >= 7 || b < end - 1);
+        const bool reset = upd && eb1 == eb - 2;
+        const int dec = upd && !reset && eb1 > eb ? 1 : 0;
+        const int D = (int)wave_incl_scan_u32((uint32_t)dec);
+        const int rix = wave_incl_scan_max(reset ? b : NEG);
+        const int Dr = __shfl(D, rix < 0 ? 0 : rix, 64);
+        if (rix >= 0) { lc = (rix < 7 ? 384 : 320) - 64 * (D - Dr); lc = lc < 0 ? 0 : lc; }
+        const int l19 = __builtin_amdgcn_readlane(lc, 19);
+        lc = b == 20 ? (l19 > 128 ? l19 - 128 : 0) : b == 21 ? (l19 > 256 ? l19 - 256 : 0) : b >= 22 ? 0 : lc;
+        const unsigned long long stopm = __ballot(b >= 3 && b < 7 && !(eb > ebm));
+        bA = stopm ? __builtin_ctzll(stopm) : 7;
+    }
+    // S3: leaks
+    const int seed = start == 0 ? bA - 1 : bndstart;
+    const bool in = live && b >= seed;
+    int fast = wave_incl_scan_min(in ? psd + c.fgain - b * c.fdecay : INF) + b * c.fdecay;
+    int slow = wave_incl_scan_min(in ? psd + c.sgain - b * c.sdecay : INF) + b * c.sdecay;
+    if (start != 0) {
+        const int ff = c.fast + (b - bndstart + 1) * c.fdecay, sl = c.slow + (b - bndstart + 1) * c.sdecay;
+        fast = ff < fast ? ff : fast;
+        slow = sl < slow ? sl : slow;
+    }
+    // S4: mask
+    int mask = (start == 0 && b < bA) ? psd + c.fgain + lc : (fast + lc < slow ? fast + lc : slow);
+    if (live) L.bmask[b] = (int16_t)ba_mask(c, mask, psd, b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // S5: bins
+    const int shift = bndstart - (int)L.band_of_bin[start];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bin = 64 * k + lane;
+        if (bin >= start && bin < end) bap[bin] = ba_width(L.width, (int)L.bmask[L.band_of_bin[bin] + shift] + 4 * e[bin]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // mantissa helpers
 
@@ -308,6 +381,11 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     if (lane < 50) L.hth[lane] = 0;
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
+    for (int i = lane; i < 256; i += 64) {
+        int b = i < 20 ? i : 20;
+        if (i >= 20) while (b < 49 && i >= P.tab->band_end[b - 20]) b++;
+        L.band_of_bin[i] = (uint8_t)b;
+    }
     for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
     for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
@@ -583,33 +661,34 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                     if (allzero) {
                         for (int i = lane; i < 7 * ROW; i += 64) (&L.bap[0][0])[i] = 0;
                     } else {
-                        // lane -> channel slot
-                        bool act = false;
-                        int start = 0, end = 0, bndstart = 0, mybai = 0, mydeltbae = 2, fl0 = 0, sl0 = 0;
-                        if (lane < 5) {
-                            act = lane < nf && (redo & (1 << lane));
-                            end = lane == 0 ? st.endmant[0] : lane == 1 ? st.endmant[1] : lane == 2 ? st.endmant[2]
-                                : lane == 3 ? st.endmant[3] : st.endmant[4];
-                            mybai = lane == 0 ? st.cbai[0] : lane == 1 ? st.cbai[1] : lane == 2 ? st.cbai[2]
-                                  : lane == 3 ? st.cbai[3] : st.cbai[4];
-                            mydeltbae = lane == 0 ? st.deltbae[0] : lane == 1 ? st.deltbae[1] : lane == 2 ? st.deltbae[2]
-                                      : lane == 3 ? st.deltbae[3] : st.deltbae[4];
-                        } else if (lane == 5) {
-                            act = st.lfeon && (redo & 32);
-                            end = 7;
-                            mybai = st.cbai[5];
-                            mydeltbae = 2;
-                        } else if (lane == 6) {
-                            act = st.chincpl && (redo & 64);
-                            start = st.cplstrtmant;
-                            end = st.cplendmant;
-                            bndstart = st.cplstrtbnd;
-                            mybai = st.cbai[6];
-                            mydeltbae = st.deltbae[5];
-                            fl0 = st.cplfleak << 8;
-                            sl0 = st.cplsleak << 8;
-                        }
-                        if (act && end > start) {
+                        // channel slots in turn (wave-uniform), each allocated by the whole wavefront
+                        for (int slot = 0; slot < 7; slot++) {
+                            bool act = false;
+                            int start = 0, end = 0, bndstart = 0, mybai = 0, mydeltbae = 2, fl0 = 0, sl0 = 0;
+                            if (slot < 5) {
+                                act = slot < nf && (redo & (1 << slot));
+                                end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2]
+                                    : slot == 3 ? st.endmant[3] : st.endmant[4];
+                                mybai = slot == 0 ? st.cbai[0] : slot == 1 ? st.cbai[1] : slot == 2 ? st.cbai[2]
+                                      : slot == 3 ? st.cbai[3] : st.cbai[4];
+                                mydeltbae = slot == 0 ? st.deltbae[0] : slot == 1 ? st.deltbae[1] : slot == 2 ? st.deltbae[2]
+                                          : slot == 3 ? st.deltbae[3] : st.deltbae[4];
+                            } else if (slot == 5) {
+                                act = st.lfeon && (redo & 32);
+                                end = 7;
+                                mybai = st.cbai[5];
+                                mydeltbae = 2;
+                            } else {
+                                act = st.chincpl && (redo & 64);
+                                start = st.cplstrtmant;
+                                end = st.cplendmant;
+                                bndstart = st.cplstrtbnd;
+                                mybai = st.cbai[6];
+                                mydeltbae = st.deltbae[5];
+                                fl0 = st.cplfleak << 8;
+                                sl0 = st.cplsleak << 8;
+                            }
+                            if (!(act && end > start)) continue;
                             BaCtx c;
                             c.halfrate = st.halfrate;
                             c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
@@ -618,13 +697,13 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                             c.sgain = k_slowgain[(st.bai >> 5) & 3];
                             c.dbknee = k_dbpb[(st.bai >> 3) & 3];
                             c.hth = L.hth;
-                            c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[lane == 6 ? 5 : lane];
+                            c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[slot == 6 ? 5 : slot];
                             const int fl = k_floors[st.bai & 7];
                             c.snroffset = 960 - 64 * st.csnroffst - 4 * (mybai >> 3) + fl;
                             c.floor = fl >> 5;
                             c.fast = fl0;
                             c.slow = sl0;
-                            bit_allocate_lane(L, c, bndstart, start, end, L.exp[lane], L.bap[lane]);
+                            bit_allocate_wave(L, c, bndstart, start, end, L.exp[slot], L.bap[slot], lane);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

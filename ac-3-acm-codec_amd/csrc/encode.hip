@@ -856,6 +856,19 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         //      the assumption that each one fits; the verdicts are then consumed in the reference's order
         //      and everything after the first surprise is discarded. ----
         const int budget = 16 * fs - frame_bits;
+        // bit 8*ch + b: block b sends new exponents for channel ch; band of bins lane, 64+lane, 128+lane, 192+lane
+        uint64_t run_starts = 0;
+        for (int ch = 0; ch < nch; ch++) {
+            const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
+            run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
+        }
+        const uint32_t bandoff = (uint32_t)L.band_of_bin[lane] | ((uint32_t)L.band_of_bin[64 + lane] << 8) |
+                                 ((uint32_t)L.band_of_bin[128 + lane] << 16) | ((uint32_t)L.band_of_bin[192 + lane] << 24);
+        // sweep lengths in 64-coefficient steps: per run of exponent reuse vs. per block
+        int run_steps = 0;
+        for (int ch = 0; ch < nch; ch++)
+            run_steps += __popc((uint32_t)(run_starts >> (8 * ch)) & 0x3f) * ((P.lfe && ch == nch - 1) ? 1 : (nbc + 63) >> 6);
+        const int item_steps = 6 * ((T + 63) >> 6);
         SnrSearch ss{csnr_prev, 0, 0, false};
         for (;;) {
             int so[3], n_cand = 0;
@@ -870,24 +883,60 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                 }
             }
             if (n_cand == 0) break;
-            int total[3] = {0, 0, 0};
-#pragma unroll 1
-            for (int b = 0; b < 6; b++) {
-                uint32_t acc[3] = {0, 0, 0};
-                const uint8_t *Eb = &L.E[b * 6][0];
-                const int16_t *Mb = &L.mask[b * 6][0];
+            // Bit allocation is a function of the (encoded) exponents alone, so a block that reuses a channel's
+            // exponents has that channel's counts of the block that sent them: every run of blocks is counted
+            // once, 64 bins per step, and added to the per-lane accumulators of all blocks of the run.
+            uint32_t acc[6][3];
 #pragma unroll
-                for (int k = 0; k < RT; k++) {
-                    if (64 * k >= T) continue;                              // wave-uniform
-                    const int e = Eb[desc[k] & 0xffff], m = Mb[desc[k] >> 16];
-                    const int d4 = ((vmask >> k) & 1) ? 320 - 16 * e : -(1 << 20);
+            for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
+            if (run_steps <= item_steps)
+            for (int ch = 0; ch < nch; ch++) {
+                const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
+                int b0 = 0;
+                while (b0 < 6) {
+                    const int b1 = __builtin_ctz(starts >> (b0 + 1)) + b0 + 1;
+                    const uint8_t *Er = &L.E[b0 * 6 + ch][0];
+                    const int16_t *Mr = &L.mask[b0 * 6 + ch][0];
+                    uint32_t sum[3] = {0, 0, 0};
 #pragma unroll
-                    for (int c = 0; c < 3; c++) acc[c] += L.bitlut[lut_index(d4, m, so[c])];
+                    for (int c = 0; c < 4; c++) {
+                        if (64 * c >= n) continue;                      // wave-uniform
+                        const int bin = 64 * c + lane;
+                        const int e = Er[bin], m = Mr[(bandoff >> (8 * c)) & 0xff];
+                        const int d4 = bin < n ? 320 - 16 * e : -(1 << 20);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) sum[k] += L.bitlut[lut_index(d4, m, so[k])];
+                    }
+#pragma unroll
+                    for (int B = 0; B < 6; B++)
+                        if (b0 <= B && B < b1) { acc[B][0] += sum[0]; acc[B][1] += sum[1]; acc[B][2] += sum[2]; }
+                    b0 = b1;
                 }
+            }
+            else {
+                // many new exponent sets: the plain sweep over every block's coefficients is shorter
+#pragma unroll
+                for (int B = 0; B < 6; B++) {
+                    const uint8_t *Eb = &L.E[B * 6][0];
+                    const int16_t *Mb = &L.mask[B * 6][0];
+#pragma unroll
+                    for (int k = 0; k < RT; k++) {
+                        if (64 * k >= T) continue;                          // wave-uniform
+                        const int e = Eb[desc[k] & 0xffff], m = Mb[desc[k] >> 16];
+                        const int d4 = ((vmask >> k) & 1) ? 320 - 16 * e : -(1 << 20);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) acc[B][c] += L.bitlut[lut_index(d4, m, so[c])];
+                    }
+                }
+            }
+            int total[3] = {0, 0, 0};
+#pragma unroll
+            for (int B = 0; B < 6; B++) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const uint32_t sa = wave_sum_u32((acc[c] & 0x3ffu) | (((acc[c] >> 10) & 63u) << 16));
-                    const uint32_t sb = wave_sum_u32(((acc[c] >> 16) & 63u) | (((acc[c] >> 22) & 63u) << 16));
+                    const uint32_t sa = wave_sum_u32((acc[B][c] & 0x3ffu) | (((acc[B][c] >> 10) & 63u) << 16));
+                    const uint32_t sb = wave_sum_u32(((acc[B][c] >> 16) & 63u) | (((acc[B][c] >> 22) & 63u) << 16));
                     const int bits = sa & 0xffff, n1 = sa >> 16, n2 = sb & 0xffff, n4 = sb >> 16;
                     total[c] += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
                 }

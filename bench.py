@@ -117,6 +117,10 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     ph = torch.rand((S, 1, 6), device=dev, generator=g) * 6.28
     fr = 0.01 * torch.arange(1, 7, device=dev, dtype=torch.float32)
     pcm = 8000.0 * torch.sin(ph + fr * t[None, :, None]) + (torch.rand((S, 1536, 6), device=dev, generator=g) - 0.5) * 4096
+    # level steps (x1 / x1/32 per 512-sample segment and channel) so that frames carry a realistic mix of new and
+    # reused exponent sets: a stationary signal would reuse block 0's exponents five times in every channel
+    env = torch.where(torch.rand((S, 3, 1, 6), device=dev, generator=g) < 0.5, 1.0, 1.0 / 32)
+    pcm = (pcm.reshape(S, 3, 512, 6) * env).reshape(S, 1536, 6)
     pcm = pcm.round().clamp(-32768, 32767).to(torch.int16).reshape(S, 1, 1536, 6).contiguous()
     last = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
     csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
