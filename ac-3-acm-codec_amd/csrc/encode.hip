@@ -1028,6 +1028,11 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                 const uint8_t *Eb = &L.E[b * 6][0];
                 const int16_t *Mb = &L.mask[b * 6][0];
                 const int32_t *mdb = md + (size_t)b * nch * 256;
+                // all of the block's coefficients in flight before the first step (the fences below would
+                // otherwise expose one HBM round trip per step)
+                int coef[RT];
+#pragma unroll
+                for (int k = 0; k < RT; k++) coef[k] = 64 * k < T ? mdb[desc[k] & 0xffff] : 0;
                 int b3 = 0, b5 = 0, b11 = 0;
 #pragma unroll
                 for (int k = 0; k < RT; k++) {
@@ -1038,7 +1043,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                     const int d4 = valid ? 320 - 16 * ex : -(1 << 20);
                     const uint32_t lut = L.bitlut[lut_index(d4, m, snroffset)];
                     const int bp = (int)(lut >> 28);
-                    const int c = mdb[eo];
+                    const int c = coef[k];
                     const int e = ex - (int)L.shiftv[b * 6 + (eo >> 8)];
                     if (P.tap_bap && valid) P.tap_bap[(fidx * 6 + b) * nch * 256 + eo] = (uint8_t)bp;
 

@@ -147,6 +147,10 @@ def gen_pcm(nframes, nch=6, seed=12345, kind="tones"):
     noise : full-scale white noise (stresses bit allocation, many new-exponent blocks)
     quiet : digital silence with an occasional +-1 (exp 24, zero bap, dither path)
     music : a few in-band partials per channel, low noise (codes well: SNR check)
+    bursts: tones whose level jumps x1 <-> x1/64 at random block boundaries per channel (new exponent sets in most
+            blocks: D15/D25/D45 mixes, bit allocation in most blocks)
+    strobe: the same with the level alternating every block (new exponents in all 36 channel-blocks: the encoder's
+            per-block search sweep)
     """
     n = nframes * 1536
     rng = np.random.default_rng(seed)
@@ -163,6 +167,13 @@ def gen_pcm(nframes, nch=6, seed=12345, kind="tones"):
             for k in range(4):
                 out[:, c] += 2500 * np.sin(2 * np.pi * (110.0 * (c + 1) * (k + 1) / 48000.0) * t + k)
             out[:, c] += rng.integers(-8, 9, n)
+        elif kind == "bursts":
+            base = 12000 * np.sin(0.013 * (c + 1) * t) + rng.integers(-3000, 3001, n)
+            gain = np.where(rng.random(n // 256) < 0.5, 1.0, 1.0 / 64)
+            out[:, c] = base * np.repeat(gain, 256)
+        elif kind == "strobe":
+            base = 12000 * np.sin(0.013 * (c + 1) * t) + rng.integers(-3000, 3001, n)
+            out[:, c] = base * np.repeat(np.where(np.arange(n // 256) % 2 == 0, 1.0, 1.0 / 64), 256)
         else:
             raise ValueError(kind)
     return np.clip(np.round(out), -32768, 32767).astype(np.int16)

@@ -79,7 +79,7 @@ def _gpu_decode(engine, frames, flags, level, bias, dynrng=1, taps=True):
     return pcm, status, t, lfsr.cpu().numpy().astype(np.int64) & 0xffff
 
 
-@pytest.mark.parametrize("kind", ["tones", "noise", "quiet", "music"])
+@pytest.mark.parametrize("kind", ["tones", "noise", "quiet", "music", "bursts"])
 def test_decode_5_1_all_stages(engine, kind):
     S, F = 6, 3
     frames = _streams(kind, S, F)

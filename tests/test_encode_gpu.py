@@ -72,7 +72,7 @@ def _gpu(engine, pcm_streams, nch, bitrate, freq=48000, chmap=H.CHMAP6, taps=Tru
     return np.concatenate([a.cpu().numpy(), b.cpu().numpy()], axis=1)[:, :, :fb], None
 
 
-@pytest.mark.parametrize("kind", ["tones", "noise", "quiet", "music"])
+@pytest.mark.parametrize("kind", ["tones", "noise", "quiet", "music", "bursts", "strobe"])
 def test_encode_5_1_all_stages(engine, kind):
     S, F = 5, 3
     pcm = [H.gen_pcm(F, 6, seed=31 + 7 * s, kind=kind) for s in range(S)]
