@@ -235,7 +235,7 @@ struct MaskTabs {
     uint8_t band_start[52];
 };
 
-struct PackLDS {
+struct alignas(16) PackLDS {
     uint8_t E[36][256];         // encoded exponents   [blk*6+ch]
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
     uint32_t gtab[3][128];      // 3/5/11-level codes being assembled: code (bits 0..6) | bit offset << 8
@@ -791,23 +791,38 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
         // ---- encoded exponents, masking curves, strategies and exponent bit counts from enc_exp_kernel ----
-        const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
-        for (int r = 0; r < 36; r++) {
-            const int b = r / 6, ch = r - 6 * b;
-            uint32_t v = 0x18181818u;
-            if (ch < nch) v = *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane);
-            *reinterpret_cast<uint32_t *>(&L.E[r][4 * lane]) = v;
-        }
         {
+            // 6*nch rows of 256 bytes, 16 bytes per lane and step, all loads of the frame in flight together
+            const uint4 *ge = reinterpret_cast<const uint4 *>(P.eexp + fidx * 6 * nch * 256);
+            uint4 ev[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int i = lane + 64 * j;
+                ev[j] = i < 6 * nch * 16 ? ge[i] : make_uint4(0, 0, 0, 0);
+            }
             const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
-            for (int i = lane; i < 6 * nch * 25; i += 64) {
+            uint32_t mv[15];
+#pragma unroll
+            for (int j = 0; j < 15; j++) {
+                const int i = lane + 64 * j;
+                mv[j] = i < 6 * nch * 25 ? gm[i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const int i = lane + 64 * j;
+                const int row = i >> 4, b = row / nch, ch = row - b * nch;
+                if (i < 6 * nch * 16) reinterpret_cast<uint4 *>(&L.E[b * 6 + ch][0])[i & 15] = ev[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 15; j++) {
+                const int i = lane + 64 * j;
                 const int row = i / 25, w = i - 25 * row, b = row / nch, ch = row - b * nch;
-                reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = gm[i];
+                if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = mv[j];
             }
             if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
         }
         int frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
-        for (int i = lane; i < PK_FRW; i += 64) L.fr[i] = 0;
+        for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
         WAVE_SYNC();
 
         // ---- fixed side information (:880-916) ----
