@@ -61,6 +61,8 @@ struct XformLaunch {
     int n_streams, frames;
     float bias;
     MixPlan plan;
+    const int32_t *slot;    // optional per-stream state slot indices (device), see ac3mi_set_state_slots
+    int delay_stride;
 };
 
 // a52_downmix()/a52_downmix_init() semantics as a plane-mixing matrix; returns <0 if
@@ -80,6 +82,7 @@ struct DecodeLaunch {
     uint16_t *lfsr;         // [S]
     uint8_t *tap_exp;
     int8_t *tap_bap;
+    const int32_t *slot;
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 void build_dec_tables(DecTables *t, uint16_t *lfsr_seq /*[65535]*/, uint16_t *lfsr_idx /*[65536]*/);
@@ -101,6 +104,7 @@ struct EncodeLaunch {
     int32_t *ws_ebits;          // [S][F][nch]
     uint8_t *tap_eexp, *tap_bap, *tap_strat;
     int32_t *tap_snr;
+    const int32_t *slot;
 };
 hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStream_t stream);
 hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream);
@@ -126,5 +130,7 @@ struct ac3mi_ctx {
     // encode workspace (MDCT coefficients, exponents, block exponents between the two kernels)
     void *ws_enc;
     size_t ws_enc_bytes;
+    // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
+    const int32_t *slots;
     std::string err;
 };

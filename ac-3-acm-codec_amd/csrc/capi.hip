@@ -361,6 +361,7 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->tab = DeviceTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ctx->ws_enc = nullptr;
     ctx->ws_enc_bytes = 0;
+    ctx->slots = nullptr;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
     ctx->ws_coef_bytes = ctx->ws_blksw_bytes = 0;
@@ -460,6 +461,13 @@ int ac3mi_timer_stop(ac3mi_ctx *ctx, float *elapsed_ms)
     return AC3MI_OK;
 }
 
+int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    ctx->slots = d_slots;
+    return AC3MI_OK;
+}
+
 int ac3mi_xform_planes(const ac3mi_xform_desc *desc, int *n_in, int *n_out)
 {
     MixPlan plan;
@@ -493,6 +501,8 @@ int ac3mi_imdct_batch(ac3mi_ctx *ctx, const ac3mi_xform_desc *desc, const float 
     L.coef = d_coeffs;
     L.blksw = d_blksw;
     L.delay = d_delay;
+    L.slot = ctx->slots;
+    L.delay_stride = 6 * 128;
     L.pcm = d_pcm;
     L.n_streams = n_streams;
     L.frames = frames_per_stream;
@@ -603,6 +613,7 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     D.blksw = blksw;
     D.status = d_status;
     D.lfsr = d_lfsr;
+    D.slot = ctx->slots;
     D.tap_exp = taps ? taps->d_exp : nullptr;
     D.tap_bap = taps ? taps->d_bap : nullptr;
     HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
@@ -610,6 +621,8 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     X.coef = coef;
     X.blksw = blksw;
     X.delay = d_delay;
+    X.slot = ctx->slots;
+    X.delay_stride = 6 * 128;
     X.pcm = d_pcm;
     X.n_streams = n_streams;
     X.frames = frames_per_stream;
@@ -691,6 +704,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     E.pcm = d_pcm;
     E.last = d_last;
     E.csnr = d_csnroffst;
+    E.slot = ctx->slots;
     E.frames = d_frames;
     E.frame_stride = frame_stride;
     E.n_streams = n_streams;

@@ -131,6 +131,7 @@ struct DecodeParams {
     int dynrng_on;
     int acmod, lfeon;       // expected coded configuration (frame 0 of the batch)
     int n_in, nfchans;
+    const int32_t *slot;    // optional: stream s keeps its LFSR state in lfsr_state[slot[s]]
 };
 
 // ---------------------------------------------------------------------------
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     for (int i = 0; i < 7; i++) st.cbai[i] = 0;
     for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
     st.cplfleak = st.cplsleak = 0;
-    st.lfsr = P.lfsr_state[s];
+    const int sslot = P.slot ? P.slot[s] : s;
+    st.lfsr = P.lfsr_state[sslot];
     int hth_fscod = -1;
 
     for (int f = 0; f < P.frames_per_stream; f++) {
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
         }
         if (lane == 0) P.status[fidx] = status;
     }
-    if (lane == 0) P.lfsr_state[s] = (uint16_t)st.lfsr;
+    if (lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
 }
 
 }  // namespace ac3mi
@@ -917,6 +919,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     P.blksw = L.blksw;
     P.status = L.status;
     P.lfsr_state = L.lfsr;
+    P.slot = L.slot;
     P.tap_exp = L.tap_exp;
     P.tap_bap = L.tap_bap;
     P.lfsr_seq = tab.lfsr_seq;

@@ -51,6 +51,7 @@ struct MdctParams {
     const EncTables *tab;
     int n_streams, frames, nch;
     uint8_t chmap[8];
+    const int32_t *slot;        // optional: stream s keeps its history in slot[s] (stride 6*256 samples)
 };
 
 struct c16 { int16_t re, im; };
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
             int16_t oldv;
             if (blk > 0) oldv = frame_pcm[(size_t)((blk - 1) * 256 + j) * P.nch];
             else if (f > 0) oldv = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];      // block 5 of the previous frame
-            else oldv = P.last[((size_t)s * P.nch + ch) * 256 + j];
+            else oldv = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
             const int16_t newv = frame_pcm[(size_t)(blk * 256 + j) * P.nch];
             // window (:1686-1693)
             in[j] = (int16_t)((oldv * win[j]) >> 15);
@@ -207,6 +208,7 @@ struct PackParams {
     const int32_t *ebits;       // [S][F][nch] bits of the coded exponents
     const int8_t *shift;
     int32_t *csnr_state;        // [S] in/out
+    const int32_t *slot;        // optional: stream s uses csnr_state[slot[s]]
     uint8_t *frames;            // [S][F][stride]
     const EncTables *tab;
     // taps (optional)
@@ -783,7 +785,8 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
     const int T = nfbw * nbc + (P.lfe ? 7 : 0);
     const int fs = P.frame_words;
 
-    int csnr_prev = P.csnr_state[s];
+    const int sslot = P.slot ? P.slot[s] : s;
+    int csnr_prev = P.csnr_state[sslot];
 
     for (int f = 0; f < P.frames_per_stream; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         }
         WAVE_SYNC();
     }
-    if (lane == 0) P.csnr_state[s] = csnr_prev;
+    if (lane == 0) P.csnr_state[sslot] = csnr_prev;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1175,6 +1178,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     M.frames = E.frames_per_stream;
     M.nch = c.nch;
     for (int i = 0; i < 8; i++) M.chmap[i] = E.chmap[i];
+    M.slot = E.slot;
     hipLaunchKernelGGL(enc_mdct_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1203,6 +1207,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.ebits = E.ws_ebits;
     P.shift = E.ws_shift;
     P.csnr_state = E.csnr;
+    P.slot = E.slot;
     P.frames = E.frames;
     P.tab = tab.enc;
     P.tap_eexp = E.tap_eexp;
@@ -1240,21 +1245,24 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
 }
 
 __global__ void enc_history_kernel(const int16_t *pcm, int16_t *last, int n_streams, int frames, int nch, const uint8_t c0,
-                                   const uint8_t c1, const uint8_t c2, const uint8_t c3, const uint8_t c4, const uint8_t c5)
+                                   const uint8_t c1, const uint8_t c2, const uint8_t c3, const uint8_t c4, const uint8_t c5,
+                                   const int32_t *slot)
 {
     const uint8_t chmap[6] = {c0, c1, c2, c3, c4, c5};
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // (s*nch + ch)*256 + j
     if (idx >= n_streams * nch * 256) return;
     const int j = idx & 255, ch = (idx >> 8) % nch, s = (idx >> 8) / nch;
     const int16_t *fp = pcm + ((size_t)s * frames + (frames - 1)) * 1536 * nch;
-    last[idx] = fp[(size_t)(5 * 256 + j) * nch + chmap[ch]];
+    const int16_t v = fp[(size_t)(5 * 256 + j) * nch + chmap[ch]];
+    if (slot) last[((size_t)slot[s] * 6 + ch) * 256 + j] = v;
+    else last[idx] = v;
 }
 
 hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream)
 {
     const int n = E.n_streams * E.cfg.nch * 256;
     hipLaunchKernelGGL(enc_history_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, E.pcm, E.last, E.n_streams,
-                       E.frames_per_stream, E.cfg.nch, E.chmap[0], E.chmap[1], E.chmap[2], E.chmap[3], E.chmap[4], E.chmap[5]);
+                       E.frames_per_stream, E.cfg.nch, E.chmap[0], E.chmap[1], E.chmap[2], E.chmap[3], E.chmap[4], E.chmap[5], E.slot);
     return hipGetLastError();
 }
 

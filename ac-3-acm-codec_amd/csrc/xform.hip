@@ -30,6 +30,8 @@ struct XformParams {
     int n_in, n_out, nfchans, in_lfe;
     float bias;
     int8_t mix[6][6];
+    const int32_t *slot;        // optional: stream s keeps its overlap state in slot[s]
+    int delay_stride;           // floats per state slot (n_out * 128 without slots)
 };
 
 // long-block input pattern: lane l8 owns m = 8*n1 + l8
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     const int o = chain - s * P.n_out;
     // overlap tail of this chain
     float2 dl[8];
-    float *dptr = P.delay + (size_t)chain * 128;
+    float *dptr = P.delay + (size_t)(P.slot ? P.slot[s] : s) * P.delay_stride + (size_t)o * 128;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
@@ -187,6 +189,8 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     P.coef = L.coef;
     P.blksw = L.blksw;
     P.delay = L.delay;
+    P.slot = L.slot;
+    P.delay_stride = L.slot ? L.delay_stride : L.plan.n_out * 128;
     P.pcm = L.pcm;
     P.tw_long = tab.tw_long;
     P.tw_short = tab.tw_short;

@@ -93,6 +93,13 @@ typedef struct {
     float bias;
 } ac3mi_xform_desc;
 
+/* Optional state-slot indirection (new, for hosts that multiplex many live streams over a pool of state
+ * slots: include/ac3mi_stream.h).  While d_slots is non-NULL, stream s of every following ac3mi_imdct_batch /
+ * ac3mi_decode_batch / ac3mi_encode_batch call keeps its carry-over state in slot d_slots[s] (device array of
+ * n_streams int32) of the state arrays passed to that call, with fixed slot strides: d_delay 6*128 floats,
+ * d_lfsr 1, d_last 6*256 samples, d_csnroffst 1.  Pass NULL to return to "stream s uses entry s". */
+int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
+
 /* Number of input planes (lfeon + fbw channels of acmod) and of output planes
  * for a descriptor; negative on an invalid combination. */
 int ac3mi_xform_planes(const ac3mi_xform_desc *desc, int *n_in, int *n_out);
