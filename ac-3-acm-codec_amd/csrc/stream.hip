@@ -13,6 +13,7 @@
 
 #include <map>
 #include <string.h>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -84,6 +85,23 @@ int frame_bytes_for(int kbps, uint32_t rate)
 
 enum Stop { STOP_DONE = 0, STOP_DECODE = 1, STOP_ENCODE = 2 };
 
+// the per-stream host work (buffering state machines, staging copies) is independent per stream
+template <class F> void parallel_for(int n, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw : 1);
+    if (nt > 16) nt = 16;
+    if (n < 512 || nt < 2) { for (int i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) {
+        const int a = t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        th.emplace_back([=] { for (int i = a; i < b; i++) f(i); });
+    }
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 struct ac3mi_pool {
@@ -116,7 +134,8 @@ struct ac3mi_stream {
     uint8_t *bufptr, *bufend;
     int blocks;                     // decode: blocks not yet handed out; encode: bytes not yet handed out
     int flags;                      // msd->flags
-    int16_t pcm[6][256 * 6];        // decode: the current frame's blocks, interleaved for dst.channels
+    int16_t pcm[6][256 * 6];        // decode: blocks of the current frame that are still owed, interleaved for dst.channels
+    const uint8_t *pcm_cur;         // where the current frame's six blocks are: the pool's staging right after a batch, else pcm
     // per-call locals of the reference's functions, kept across stops
     ac3mi_stream_header *hdr;
     const uint8_t *src_p;
@@ -135,7 +154,7 @@ namespace {
 void emit_block(ac3mi_stream *st, int index)
 {
     const int sr = 512 * st->dst.channels;
-    memcpy(st->dst_p, st->pcm[index], (size_t)sr);
+    memcpy(st->dst_p, st->pcm_cur + (size_t)index * sr, (size_t)sr);
     st->hdr->dst_used += (uint32_t)sr;
     st->dst_p += sr;
 }
@@ -172,9 +191,14 @@ Stop run_decode(ac3mi_stream *st)
         sr = 512 * nch;
         fs = ((long long)sh->src_len * 2 - sh->src_used) < (long long)st->fs_next ? 1 : 0;
         for (st->blocks = 6; st->blocks > fs; --st->blocks) {
-            if ((st->dst_left -= sr) < 0) { st->phase = 3; return STOP_DONE; }
+            if ((st->dst_left -= sr) < 0) break;
             emit_block(st, 6 - st->blocks);
         }
+        // blocks still owed move out of the pool's staging (it is reused by the next round)
+        for (int b = 6 - st->blocks; b < 6 && st->pcm_cur != (const uint8_t *)st->pcm; b++)
+            memcpy((uint8_t *)st->pcm + (size_t)b * sr, st->pcm_cur + (size_t)b * sr, (size_t)sr);
+        st->pcm_cur = (const uint8_t *)st->pcm;
+        if (st->dst_left < 0) { st->phase = 3; return STOP_DONE; }
         fs = 128;
         goto refill;
     }
@@ -308,9 +332,16 @@ int fail(ac3mi_pool *p, int code, const char *what)
 }
 
 // one batched decode for the streams in `group` (same coded configuration and request)
-int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group)
+int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int base)
 {
+    // staging entries [base, base + k): results stay there until the state machines have taken them
     ac3mi_ctx *ctx = p->ctx;
+    int32_t *d_slots = p->d_slots + base, *h_slots = p->h_slots + base;
+    uint8_t *d_frames = p->d_frames + (size_t)base * FRAME_STRIDE, *h_frames = p->h_frames + (size_t)base * FRAME_STRIDE;
+    float *d_pcm = p->d_pcm + (size_t)base * 6 * 6 * 256;
+    int16_t *d_s16 = (int16_t *)((uint8_t *)p->d_s16 + (size_t)base * PCM_FRAME_BYTES), *h_s16 = (int16_t *)((uint8_t *)p->h_s16 + (size_t)base * PCM_FRAME_BYTES);
+    uint32_t *d_status = p->d_status + base, *h_status = p->h_status + base;
+    (void)d_pcm; (void)d_status; (void)h_status;
     const int k = (int)group.size();
     const ac3mi_stream *s0 = group[0];
     ac3mi_decode_desc d;
@@ -325,37 +356,43 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group)
     const bool grantable = ac3mi_decode_planes(&d, &n_out, &granted) == AC3MI_OK && n_out == s0->dst.channels;
     if (!grantable) {
         // liba52 would hand fewer (or other) planes than the destination format has: silence (see header)
-        for (ac3mi_stream *st : group) memset(st->pcm, 0, sizeof st->pcm);
+        for (ac3mi_stream *st : group) { memset(st->pcm, 0, sizeof st->pcm); st->pcm_cur = (const uint8_t *)st->pcm; }
         // the frame still advances the stream's dither / overlap state in the reference; it cannot be reproduced
         return AC3MI_MMSYSERR_NOERROR;
     }
-    for (int i = 0; i < k; i++) {
-        p->h_slots[i] = group[i]->slot;
-        memcpy(p->h_frames + (size_t)i * FRAME_STRIDE, group[i]->bufptr, (size_t)s0->frame_bytes);
-    }
-    if (ac3mi_memcpy_h2d(ctx, p->d_slots, p->h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_h2d(ctx, p->d_frames, p->h_frames, (size_t)k * FRAME_STRIDE) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    ac3mi_set_state_slots(ctx, p->d_slots);
-    int rc = ac3mi_decode_batch(ctx, &d, p->d_frames, FRAME_STRIDE, k, 1, p->d_delay, p->d_lfsr, p->d_pcm, p->d_status, NULL);
-    if (rc == AC3MI_OK) rc = ac3mi_convert_s16_batch(ctx, p->d_pcm, p->d_s16, granted, (size_t)k * 6);
+    parallel_for(k, [&](int i) {
+        h_slots[i] = group[i]->slot;
+        memcpy(h_frames + (size_t)i * FRAME_STRIDE, group[i]->bufptr, (size_t)s0->frame_bytes);
+    });
+    if (ac3mi_memcpy_h2d(ctx, d_slots, h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (ac3mi_memcpy_h2d(ctx, d_frames, h_frames, (size_t)k * FRAME_STRIDE) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    ac3mi_set_state_slots(ctx, d_slots);
+    int rc = ac3mi_decode_batch(ctx, &d, d_frames, FRAME_STRIDE, k, 1, p->d_delay, p->d_lfsr, d_pcm, d_status, NULL);
+    if (rc == AC3MI_OK) rc = ac3mi_convert_s16_batch(ctx, d_pcm, d_s16, granted, (size_t)k * 6);
     ac3mi_set_state_slots(ctx, NULL);
     if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch");
     const size_t blk = (size_t)256 * n_out * 2;
-    if (ac3mi_memcpy_d2h(ctx, p->h_s16, p->d_s16, (size_t)k * 6 * blk) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_d2h(ctx, p->h_status, p->d_status, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (ac3mi_memcpy_d2h(ctx, h_s16, d_s16, (size_t)k * 6 * blk) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (ac3mi_memcpy_d2h(ctx, h_status, d_status, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
     for (int i = 0; i < k; i++) {
         ac3mi_stream *st = group[i];
-        st->status = p->h_status[i];
+        st->status = h_status[i];
         st->granted = (int)((st->status >> 16) & 0xff);
-        for (int b = 0; b < 6; b++) memcpy(st->pcm[b], (const uint8_t *)p->h_s16 + ((size_t)i * 6 + b) * blk, blk);
+        st->pcm_cur = (const uint8_t *)h_s16 + (size_t)i * 6 * blk;      // handed out (or saved) by run_decode before the next batch
     }
     return AC3MI_MMSYSERR_NOERROR;
 }
 
-int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group)
+int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int base)
 {
     ac3mi_ctx *ctx = p->ctx;
+    int32_t *d_slots = p->d_slots + base, *h_slots = p->h_slots + base;
+    uint8_t *d_frames = p->d_frames + (size_t)base * FRAME_STRIDE, *h_frames = p->h_frames + (size_t)base * FRAME_STRIDE;
+    float *d_pcm = p->d_pcm + (size_t)base * 6 * 6 * 256;
+    int16_t *d_s16 = (int16_t *)((uint8_t *)p->d_s16 + (size_t)base * PCM_FRAME_BYTES), *h_s16 = (int16_t *)((uint8_t *)p->h_s16 + (size_t)base * PCM_FRAME_BYTES);
+    uint32_t *d_status = p->d_status + base, *h_status = p->h_status + base;
+    (void)d_pcm; (void)d_status; (void)h_status;
     const int k = (int)group.size();
     const ac3mi_stream *s0 = group[0];
     const int nch = s0->src.channels;
@@ -365,21 +402,21 @@ int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group)
     const int stride = (fb + 3) & ~3;
     uint8_t chmap[8];
     channel_map(nch, chmap);
-    uint8_t *h_in = (uint8_t *)p->h_s16;
-    for (int i = 0; i < k; i++) {
-        p->h_slots[i] = group[i]->slot;
+    uint8_t *h_in = (uint8_t *)h_s16;
+    parallel_for(k, [&](int i) {
+        h_slots[i] = group[i]->slot;
         memcpy(h_in + (size_t)i * in_bytes, group[i]->buf, in_bytes);
-    }
-    if (ac3mi_memcpy_h2d(ctx, p->d_slots, p->h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_h2d(ctx, p->d_s16, h_in, (size_t)k * in_bytes) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    ac3mi_set_state_slots(ctx, p->d_slots);
-    const int rc = ac3mi_encode_batch(ctx, &d, p->d_s16, chmap, p->d_last, p->d_csnr, p->d_frames, stride, k, 1, NULL);
+    });
+    if (ac3mi_memcpy_h2d(ctx, d_slots, h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (ac3mi_memcpy_h2d(ctx, d_s16, h_in, (size_t)k * in_bytes) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    ac3mi_set_state_slots(ctx, d_slots);
+    const int rc = ac3mi_encode_batch(ctx, &d, d_s16, chmap, p->d_last, p->d_csnr, d_frames, stride, k, 1, NULL);
     ac3mi_set_state_slots(ctx, NULL);
     if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "encode batch");
-    if (ac3mi_memcpy_d2h(ctx, p->h_frames, p->d_frames, (size_t)k * stride) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (ac3mi_memcpy_d2h(ctx, h_frames, d_frames, (size_t)k * stride) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
     for (int i = 0; i < k; i++) {
-        memcpy(group[i]->frame, p->h_frames + (size_t)i * stride, (size_t)fb);
+        memcpy(group[i]->frame, h_frames + (size_t)i * stride, (size_t)fb);
         group[i]->frame_bytes = fb;
     }
     return AC3MI_MMSYSERR_NOERROR;
@@ -518,6 +555,7 @@ int ac3mi_stream_open(ac3mi_pool *pool, const ac3mi_wavefmt *src, const ac3mi_wa
     st->flags = 0;
     st->phase = 3;
     st->hdr = nullptr;
+    st->pcm_cur = (const uint8_t *)st->pcm;
     ac3mi_ctx *ctx = pool->ctx;
     bool ok = true;
     if (decode) {
@@ -605,18 +643,22 @@ int ac3mi_stream_convert_many(ac3mi_stream *const *streams, ac3mi_stream_header 
     typedef std::tuple<int, int, int, int, int, int> Key;
     for (;;) {
         std::map<Key, std::vector<ac3mi_stream *>> dec, enc;
+        std::vector<int> stops((size_t)n, STOP_DONE);
+        parallel_for(n, [&](int i) {
+            ac3mi_stream *st = streams[i];
+            if (st->phase != 3) stops[(size_t)i] = st->decode ? run_decode(st) : run_encode(st);
+        });
         for (int i = 0; i < n; i++) {
             ac3mi_stream *st = streams[i];
-            if (st->phase == 3) continue;
-            const Stop s = st->decode ? run_decode(st) : run_encode(st);
-            if (s == STOP_DECODE)
+            if (stops[(size_t)i] == STOP_DECODE)
                 dec[Key(st->acmod, st->lfeon, st->frame_bytes, st->req_flags, (int)(st->driver_flags & AC3MI_ACM_DYNAMICRANGE), st->dst.channels)].push_back(st);
-            else if (s == STOP_ENCODE)
+            else if (stops[(size_t)i] == STOP_ENCODE)
                 enc[Key(st->enc_rate, st->enc_bitrate, st->src.channels, 0, 0, 0)].push_back(st);
         }
         if (dec.empty() && enc.empty()) break;
-        for (auto &g : dec) { const int rc = decode_group(pool, g.second); if (rc) return rc; }
-        for (auto &g : enc) { const int rc = encode_group(pool, g.second); if (rc) return rc; }
+        int base = 0;
+        for (auto &g : dec) { const int rc = decode_group(pool, g.second, base); if (rc) return rc; base += (int)g.second.size(); }
+        for (auto &g : enc) { const int rc = encode_group(pool, g.second, base); if (rc) return rc; base += (int)g.second.size(); }
     }
     return AC3MI_MMSYSERR_NOERROR;
 }
