@@ -172,7 +172,8 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
                      "algorithmic_bytes_per_frame": nbytes}
     ok = int((status & 0x1ff).max().item()) == 0
     res["decode"]["all_frames_ok"] = ok
-    res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
+    if dist is None:           # host-side work on up to 16 threads: single-process runs only
+        res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
                    "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
     return res
