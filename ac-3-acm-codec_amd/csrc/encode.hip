@@ -888,19 +888,49 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             run_steps += __popc((uint32_t)(run_starts >> (8 * ch)) & 0x3f) * ((P.lfe && ch == nch - 1) ? 1 : (nbc + 63) >> 6);
         const int item_steps = 6 * ((T + 63) >> 6);
         SnrSearch ss{csnr_prev, 0, 0, false};
+        // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
+        // known_f / fits_f for (csnroffst f_cc, ff > 0).  The reference asks for some offsets twice.
+        uint64_t known_c = 0, fits_c = 0;
+        uint32_t known_f = 0, fits_f = 0;
+        int f_cc = -1;
+        bool went_down = false, went_up = false;
+        auto lookup = [&](int cc, int ff, bool &fits) {
+            if (ff == 0) { fits = (fits_c >> cc) & 1; return (bool)((known_c >> cc) & 1); }
+            fits = (fits_f >> ff) & 1;
+            return cc == f_cc && ((known_f >> ff) & 1);
+        };
         for (;;) {
-            int so[3], n_cand = 0;
+            // advance the reference's loop as far as the known verdicts reach
+            int cc, ff;
+            bool more;
+            while ((more = ss.next(cc, ff))) {
+                bool fits;
+                if (!lookup(cc, ff, fits)) break;
+                if (ss.phase == 0 && !fits) went_down = true;
+                if (ss.phase == 1 && fits) went_up = true;
+                ss.consume(fits);
+            }
+            if (!more) break;
+            // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
+            // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
+            int so[3], cand_c[3], cand_f[3], n_cand = 0;
             {
                 SnrSearch ahead = ss;
-                int cc, ff;
                 while (n_cand < 3 && ahead.next(cc, ff)) {
-                    const int v = (((cc - 15) << 4) + ff) << 2;
-                    if (n_cand == 0) so[0] = so[1] = so[2] = v;
-                    so[n_cand++] = v;
-                    ahead.consume(true);
+                    bool fits;
+                    if (!lookup(cc, ff, fits)) {
+                        bool dup = false;
+                        for (int i = 0; i < n_cand; i++) dup = dup || (cand_c[i] == cc && cand_f[i] == ff);
+                        if (dup) break;
+                        const int v = (((cc - 15) << 4) + ff) << 2;
+                        if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                        cand_c[n_cand] = cc; cand_f[n_cand] = ff;
+                        so[n_cand++] = v;
+                        fits = ahead.phase == 0 ? !went_down : ahead.phase == 1 ? went_up : true;
+                    }
+                    ahead.consume(fits);
                 }
             }
-            if (n_cand == 0) break;
             // Bit allocation is a function of the (encoded) exponents alone, so a block that reuses a channel's
             // exponents has that channel's counts of the block that sent them: every run of blocks is counted
             // once, 64 bins per step, and added to the per-lane accumulators of all blocks of the run.
@@ -960,11 +990,13 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                 }
             }
             for (int i = 0; i < n_cand; i++) {
-                int cc, ff;
-                ss.next(cc, ff);
                 const bool ok = budget - total[i] >= 0;
-                ss.consume(ok);
-                if (!ok) break;
+                if (cand_f[i] == 0) { known_c |= 1ull << cand_c[i]; fits_c |= (uint64_t)ok << cand_c[i]; }
+                else {
+                    if (cand_c[i] != f_cc) { f_cc = cand_c[i]; known_f = fits_f = 0; }     // costed ahead for another csnroffst
+                    known_f |= 1u << cand_f[i];
+                    fits_f |= (uint32_t)ok << cand_f[i];
+                }
             }
         }
         int csnr = ss.csnr, fsnr = ss.fsnr;
