@@ -210,49 +210,39 @@ int main(int argc, char **argv)
     a52_state_t *state = a52_init(0);
     if (!state) { fprintf(stderr, "A52 init failed\n"); return 1; }
 
-    /* a52_decode_data (a52dec.c:240-310): 7 header bytes, then the rest of the frame; one byte dropped on a miss */
-    static uint8_t buf[3840 + 8], chunk[4096];
-    uint8_t *bufptr = buf, *bufpos = buf + 7;
-    int sample_rate = 0, flags = 0, bit_rate;
-    size_t got;
-    while ((got = fread(chunk, 1, sizeof chunk, in_file)) > 0) {
-        const uint8_t *start = chunk, *end = chunk + got;
-        while (start != end) {
-            size_t len = (size_t)(end - start);
-            if (len > (size_t)(bufpos - bufptr)) len = (size_t)(bufpos - bufptr);
-            memcpy(bufptr, start, len);
-            bufptr += len;
-            start += len;
-            if (bufptr != bufpos) continue;
-            if (bufpos == buf + 7) {
-                const int length = a52_syncinfo(buf, &flags, &sample_rate, &bit_rate);
-                if (!length) {
-                    fprintf(stderr, "skip\n");
-                    for (bufptr = buf; bufptr < buf + 6; bufptr++) bufptr[0] = bufptr[1];
-                    continue;
-                }
-                bufpos = buf + length;
-            } else {
-                float level, bias;
-                int ok = 0;
-                do {
-                    if (output_setup(sample_rate, &flags, &level, &bias)) break;
-                    if (!disable_adjust) flags |= A52_ADJUST_LEVEL;
-                    level = (float)(level * gain);
-                    if (a52_frame(state, buf, &flags, &level, bias)) break;
-                    if (disable_dynrng) a52_dynrng(state, NULL, NULL);
-                    int i;
-                    for (i = 0; i < 6; i++) {
-                        if (a52_block(state)) break;
-                        if (output_play(flags, a52_samples(state))) break;
-                    }
-                    ok = i == 6;
-                } while (0);
-                if (!ok) fprintf(stderr, "error\n");
-                bufptr = buf;
-                bufpos = buf + 7;
+    /* Elementary-stream framing with a52dec's behaviour (a52dec.c:240-310): a frame starts wherever a52_syncinfo
+     * accepts seven bytes; a position it rejects is skipped byte by byte ("skip" on stderr per byte); a frame that
+     * fails to set up or decode costs one "error" and the stream resumes after it. */
+    static uint8_t win[2 * 3840 + 4096];
+    size_t have = 0, at = 0;
+    int eof = 0;
+    for (;;) {
+        if (have - at < 3840 && !eof) {                 /* top the window up so that any frame fits */
+            memmove(win, win + at, have - at);
+            have -= at;
+            at = 0;
+            const size_t got = fread(win + have, 1, sizeof win - have, in_file);
+            have += got;
+            eof = got == 0;
+            if (!eof) continue;
+        }
+        if (have - at < 7) break;
+        int flags, sample_rate, bit_rate;
+        const int length = a52_syncinfo(win + at, &flags, &sample_rate, &bit_rate);
+        if (!length) { fprintf(stderr, "skip\n"); at++; continue; }
+        if (have - at < (size_t)length) break;          /* truncated last frame */
+        float level, bias;
+        int done = 0;
+        if (!output_setup(sample_rate, &flags, &level, &bias)) {
+            if (!disable_adjust) flags |= A52_ADJUST_LEVEL;
+            level = (float)(level * gain);
+            if (!a52_frame(state, win + at, &flags, &level, bias)) {
+                if (disable_dynrng) a52_dynrng(state, NULL, NULL);
+                while (done < 6 && !a52_block(state) && !output_play(flags, a52_samples(state))) done++;
             }
         }
+        if (done != 6) fprintf(stderr, "error\n");
+        at += (size_t)length;
     }
     output_close();
     a52_free(state);
