@@ -44,7 +44,7 @@ __device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint3
 
 struct MdctParams {
     const int16_t *pcm;         // [S][F][1536][nch] interleaved
-    int16_t *last;              // [S][nch][256] history before frame 0 (read only here)
+    int16_t *last;              // [S][nch][256] history before frame 0 (rewritten here when store_history)
     int32_t *mdct;              // [S][F][6][nch][256]
     uint8_t *expo;              // [S][F][6][nch][256]
     int8_t *shift;              // [S][F][6][nch]
@@ -52,6 +52,7 @@ struct MdctParams {
     int n_streams, frames, nch;
     uint8_t chmap[8];
     const int32_t *slot;        // optional: stream s keeps its history in slot[s] (stride 6*256 samples)
+    int store_history;          // one frame per stream: this kernel also leaves the new history (else enc_history_kernel)
 };
 
 struct c16 { int16_t re, im; };
@@ -95,6 +96,10 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
             else if (f > 0) oldv = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];      // block 5 of the previous frame
             else oldv = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
             const int16_t newv = frame_pcm[(size_t)(blk * 256 + j) * P.nch];
+            if (P.store_history && blk == 5) {
+                if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv;
+                else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv;
+            }
             // window (:1686-1693)
             in[j] = (int16_t)((oldv * win[j]) >> 15);
             in[256 + j] = (int16_t)((newv * win[255 - j]) >> 15);
@@ -604,16 +609,24 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
     }
     WAVE_SYNC();
 
-    // ---- band PSDs (:220-258): bands 0..27 are single bins; the 22 wider ones are integrated by one
-    //      lane each, two rows per sweep ----
+    // ---- band PSDs (:220-258) and masking curves (:259-367) of the blocks that send exponents; a block that
+    //      reuses them has the same curve.  Bands 0..27 are single bins; the 22 wider ones are integrated by
+    //      one lane each, two rows per sweep ----
     {
+        int rows[6], nrows = 0, src_of[6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            if (st[b] != 0) rows[nrows++] = b;                      // st[] is wave-uniform
+            src_of[b] = rows[nrows - 1];                            // block 0 always sends
+        }
         const int nsingle = n < 28 ? n : 28;
-        for (int b = 0; b < 6; b++)
-            if (lane < nsingle) L.mask[b][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[b][lane] << 7));
+        for (int i = 0; i < nrows; i++)
+            if (lane < nsingle) L.mask[rows[i]][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[rows[i]][lane] << 7));
         if (n > 28) {
-            for (int p = 0; p < 3; p++) {
-                const int r = 2 * p + (lane >> 5), band = 28 + (lane & 31);
-                const bool active = (lane & 31) < 22;
+            for (int p = 0; 2 * p < nrows; p++) {
+                const int half = lane >> 5, band = 28 + (lane & 31);
+                const int r = rows[2 * p + half < nrows ? 2 * p + half : 2 * p];
+                const bool active = (lane & 31) < 22 && 2 * p + half < nrows;
                 const int start = L.t.band_start[active ? band : 28];
                 int end1 = L.t.band_start[active ? band + 1 : 29];
                 end1 = end1 < n ? end1 : n;
@@ -632,17 +645,18 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
                 if (wdt > 0) L.mask[r][band] = (int16_t)v;
             }
         }
-    }
-    WAVE_SYNC();
-
-    // ---- masking curves (:259-367), fixed allocation codes (:861-879) ----
-    {
+        WAVE_SYNC();
+        // fixed allocation codes (:861-879)
         const int sdecaycod = 2, fdecaycod = 1, fgaincod = 4;
         const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
         const int sgain = 0x4d8, dbknee = 0x900, fgain = 128 * (fgaincod + 1);
         const int bndend = L.t.band_of_bin[n - 1] + 1;
-        for (int b = 0; b < 6; b++)
-            mask_row_wave(L.t, L.mask[b], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
+        for (int i = 0; i < nrows; i++)
+            mask_row_wave(L.t, L.mask[rows[i]], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
+        WAVE_SYNC();
+#pragma unroll
+        for (int b = 1; b < 6; b++)
+            if (src_of[b] != b && lane < 50) L.mask[b][lane] = L.mask[src_of[b]][lane];
     }
     WAVE_SYNC();
 
@@ -1211,6 +1225,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     M.nch = c.nch;
     for (int i = 0; i < 8; i++) M.chmap[i] = E.chmap[i];
     M.slot = E.slot;
+    M.store_history = E.frames_per_stream == 1;      // the only reader of last[] is this same wavefront's block 0
     hipLaunchKernelGGL(enc_mdct_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1273,6 +1288,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame
+    if (M.store_history) return hipSuccess;
     return launch_enc_history(E, stream);
 }
 
