@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                 if (st.acmod != P.acmod) hdr_ok = false;
                 const int code = b4 & 63, rate = k_kbps[code >> 1];
                 const int fbytes = st.fscod == 0 ? 4 * rate : st.fscod == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
-                if (fbytes != P.frame_bytes) hdr_ok = false;
+                if (fbytes > P.frame_bytes) hdr_ok = false;        // frame_bytes = the largest frame of the batch (44.1 kHz alternates)
             }
         }
         if (hdr_ok) {

@@ -132,9 +132,11 @@ int ac3mi_imdct_batch(ac3mi_ctx *ctx, const ac3mi_xform_desc *desc,
  *  level   a52_frame()'s *level argument;  bias: its bias argument
  *  dynrng  1 = apply the stream's dynamic-range words (liba52's default),
  *          0 = a52_dynrng(state, NULL, NULL).  A dynrng callback cannot run on the GPU.
- *  acmod, lfeon, frame_bytes   coded configuration shared by every frame of the batch
- *          (what a52_syncinfo() reports for any one of them); frames that disagree are
- *          reported in d_status and produce silence
+ *  acmod, lfeon   coded configuration shared by every frame of the batch (what a52_syncinfo()
+ *          reports for any one of them); frames that disagree are reported in d_status and
+ *          produce silence
+ *  frame_bytes    size of the largest frame of the batch (44.1 kHz streams alternate between two
+ *          sizes); every frame starts on its frame_stride slot and carries its own size
  */
 typedef struct {
     int flags;

@@ -155,3 +155,42 @@ def test_gpu_decoder_on_packer_streams(engine, acmod, lfe, fscod, bsid, fsz):
         scale_rms, scale_max = max(1.0, H.rms(want_pcm)), max(1.0, float(np.abs(want_pcm).max()))
         assert H.rms(err) <= 1e-6 * scale_rms and np.abs(err).max() <= 1e-5 * scale_max, \
             (acmod, flags, H.rms(err), np.abs(err).max(), scale_rms, scale_max)
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_frames_of_two_sizes_in_one_stream(engine):
+    """44.1 kHz streams alternate between two frame sizes (frmsizecod 2k / 2k+1): every frame sits on its stride
+    slot and carries its own size; the descriptor names the larger one."""
+    import ctypes
+    import torch
+    pkg = H.pkg()
+    S, F = 3, 4
+    a = [packer.make_stream(50 + s, F, 2, 0, fscod=1, bsid=8, frmsizecod=28) for s in range(S)]
+    b = [packer.make_stream(90 + s, F, 2, 0, fscod=1, bsid=8, frmsizecod=29) for s in range(S)]
+    fa, fb = a[0].shape[1], b[0].shape[1]
+    assert fb == fa + 2
+    stride = (fb + 3) & ~3
+    padded = np.zeros((S, F, stride), np.uint8)
+    L = H.orc()
+    want = np.zeros((S, F, 6, 2, 256), np.float32)
+    for s in range(S):
+        st = L.orc_a52_init()
+        for f in range(F):
+            fr = (a if f % 2 == 0 else b)[s][f]
+            padded[s, f, :fr.size] = fr
+            buf = np.zeros(fr.size + 64, np.uint8)
+            buf[:fr.size] = fr
+            fl, lv = H.ci(2), H.cf(1.0)
+            assert L.orc_a52_frame(st, H.P(buf, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0) == 0
+            for blk in range(6):
+                assert L.orc_a52_block(st) == 0
+                want[s, f, blk] = np.ctypeslib.as_array(L.orc_a52_samples(st), (1536,))[:512].reshape(2, 256)
+        L.orc_a52_free(st)
+    desc = pkg.DecodeDesc(flags=2, level=1.0, bias=0.0, dynrng=1, acmod=2, lfeon=0, frame_bytes=fb)
+    delay = torch.zeros((S, 2, 128), dtype=torch.float32, device="cuda")
+    lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+    pcm, status, _ = engine.decode_batch(desc, torch.from_numpy(padded).cuda(), delay, lfsr, taps=True)
+    engine.sync()
+    assert (status.cpu().numpy() & 0x1ff).max() == 0
+    err = pcm.cpu().numpy().astype(np.float64) - want
+    assert H.rms(err) <= 1e-6 * max(1.0, H.rms(want))
