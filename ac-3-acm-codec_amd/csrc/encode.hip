@@ -243,9 +243,8 @@ struct MaskTabs {
 };
 
 struct alignas(16) PackLDS {
-    uint8_t E[36][256];         // encoded exponents   [blk*6+ch]
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
-    uint32_t gtab[3][128];      // 3/5/11-level codes being assembled: code (bits 0..6) | bit offset << 8
+    uint32_t gtab[128];         // 3/5/11-level codes being assembled, rings of 32 / 32 / 64: code (bits 0..6) | bit offset << 8
     uint32_t bitlut[64];        // see lut_index
     uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
     int8_t shiftv[36];          // exp_samples of the frame
@@ -679,7 +678,6 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
 // L.bitlut[address] = plain mantissa width | (bap==1) << 10 | (bap==2) << 16 | (bap==4) << 22 | bap << 28.
 // lut_index returns the address with d4 = 4 * (80 - 4 exp) (hugely negative for a padding item: address 0,
 // bap 0, no bits).
-constexpr int RT = 18;              // coefficients per lane and block: ceil((5*223 + 7) / 64)
 
 __device__ __forceinline__ int lut_index(int d4, int mask_minus_floor, int snroffset)
 {
@@ -777,7 +775,7 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
     return __shfl(crc, 63, 64);
 }
 
-__global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
     const int lane = threadIdx.x;
@@ -807,28 +805,16 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
-        // ---- encoded exponents, masking curves, strategies and exponent bit counts from enc_exp_kernel ----
+        // ---- masking curves, strategies and exponent bit counts from enc_exp_kernel (the encoded exponents
+        //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
+        const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
         {
-            // 6*nch rows of 256 bytes, 16 bytes per lane and step, all loads of the frame in flight together
-            const uint4 *ge = reinterpret_cast<const uint4 *>(P.eexp + fidx * 6 * nch * 256);
-            uint4 ev[9];
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const int i = lane + 64 * j;
-                ev[j] = i < 6 * nch * 16 ? ge[i] : make_uint4(0, 0, 0, 0);
-            }
             const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
             uint32_t mv[15];
 #pragma unroll
             for (int j = 0; j < 15; j++) {
                 const int i = lane + 64 * j;
                 mv[j] = i < 6 * nch * 25 ? gm[i] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const int i = lane + 64 * j;
-                const int row = i >> 4, b = row / nch, ch = row - b * nch;
-                if (i < 6 * nch * 16) reinterpret_cast<uint4 *>(&L.E[b * 6 + ch][0])[i & 15] = ev[j];
             }
 #pragma unroll
             for (int j = 0; j < 15; j++) {
@@ -861,22 +847,6 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             frame_bits += 16;
         }
 
-        // ---- per-lane view of the coefficient stream: item k of a lane is coefficient 64k + lane of every
-        //      block's mantissa stream (channel-major, LFE last).  desc = E-row offset | mask index << 16 ----
-        int desc[RT];
-        uint32_t vmask = 0;
-#pragma unroll
-        for (int k = 0; k < RT; k++) {
-            const int t = 64 * k + lane;
-            int ch = t / nbc;
-            ch = ch < nfbw ? ch : nfbw;
-            int bin = t - ch * nbc;
-            const bool valid = t < T;
-            bin = valid ? bin : 0;
-            ch = valid ? ch : 0;
-            desc[k] = (ch * 256 + bin) | ((ch * 50 + L.band_of_bin[bin]) << 16);
-            vmask |= (valid ? 1u : 0u) << k;
-        }
         if (lane < 36) {
             const int b = lane / 6, ch = lane - 6 * b;
             L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
@@ -888,19 +858,18 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
         //      the assumption that each one fits; the verdicts are then consumed in the reference's order
         //      and everything after the first surprise is discarded. ----
         const int budget = 16 * fs - frame_bits;
-        // bit 8*ch + b: block b sends new exponents for channel ch; band of bins lane, 64+lane, 128+lane, 192+lane
+        // bit 8*ch + b: block b sends new exponents for channel ch
         uint64_t run_starts = 0;
         for (int ch = 0; ch < nch; ch++) {
             const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
             run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
         }
-        const uint32_t bandoff = (uint32_t)L.band_of_bin[lane] | ((uint32_t)L.band_of_bin[64 + lane] << 8) |
-                                 ((uint32_t)L.band_of_bin[128 + lane] << 16) | ((uint32_t)L.band_of_bin[192 + lane] << 24);
-        // sweep lengths in 64-coefficient steps: per run of exponent reuse vs. per block
-        int run_steps = 0;
+        const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&L.band_of_bin[4 * lane]);    // bands of bins 4*lane..+3
+        // rows (blk * 6 + ch) that start a run of exponent reuse, as a bit set
+        uint64_t row_set = 0;
         for (int ch = 0; ch < nch; ch++)
-            run_steps += __popc((uint32_t)(run_starts >> (8 * ch)) & 0x3f) * ((P.lfe && ch == nch - 1) ? 1 : (nbc + 63) >> 6);
-        const int item_steps = 6 * ((T + 63) >> 6);
+            for (int b = 0; b < 6; b++)
+                if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
         SnrSearch ss{csnr_prev, 0, 0, false};
         // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
         // known_f / fits_f for (csnroffst f_cc, ff > 0).  The reference asks for some offsets twice.
@@ -951,45 +920,34 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
             uint32_t acc[6][3];
 #pragma unroll
             for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
-            if (run_steps <= item_steps)
-            for (int ch = 0; ch < nch; ch++) {
-                const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-                const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
-                int b0 = 0;
-                while (b0 < 6) {
+            {
+                // one run-start row per step: four bins per lane from one dword (HBM/L2), the next row's dword in flight
+                uint64_t todo = row_set;
+                int r = __builtin_ctzll(todo);
+                uint32_t ev = *reinterpret_cast<const uint32_t *>(ex + ((size_t)(r / 6) * nch + (r % 6)) * 256 + 4 * lane);
+#pragma unroll 1
+                while (todo) {
+                    todo &= todo - 1;
+                    const int rn = todo ? __builtin_ctzll(todo) : r;
+                    const uint32_t evn = *reinterpret_cast<const uint32_t *>(ex + ((size_t)(rn / 6) * nch + (rn % 6)) * 256 + 4 * lane);
+                    const int b0 = r / 6, ch = r - 6 * b0;
+                    const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                    const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
                     const int b1 = __builtin_ctz(starts >> (b0 + 1)) + b0 + 1;
-                    const uint8_t *Er = &L.E[b0 * 6 + ch][0];
-                    const int16_t *Mr = &L.mask[b0 * 6 + ch][0];
+                    const int16_t *Mr = &L.mask[r][0];
                     uint32_t sum[3] = {0, 0, 0};
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (64 * c >= n) continue;                      // wave-uniform
-                        const int bin = 64 * c + lane;
-                        const int e = Er[bin], m = Mr[(bandoff >> (8 * c)) & 0xff];
-                        const int d4 = bin < n ? 320 - 16 * e : -(1 << 20);
+                    for (int j = 0; j < 4; j++) {
+                        const int e = (ev >> (8 * j)) & 0xff, m = Mr[(bandoff >> (8 * j)) & 0xff];
+                        const int d4 = 4 * lane + j < n ? 320 - 16 * e : -(1 << 20);
 #pragma unroll
                         for (int k = 0; k < 3; k++) sum[k] += L.bitlut[lut_index(d4, m, so[k])];
                     }
 #pragma unroll
                     for (int B = 0; B < 6; B++)
-                        if (b0 <= B && B < b1) { acc[B][0] += sum[0]; acc[B][1] += sum[1]; acc[B][2] += sum[2]; }
-                    b0 = b1;
-                }
-            }
-            else {
-                // many new exponent sets: the plain sweep over every block's coefficients is shorter
-#pragma unroll
-                for (int B = 0; B < 6; B++) {
-                    const uint8_t *Eb = &L.E[B * 6][0];
-                    const int16_t *Mb = &L.mask[B * 6][0];
-#pragma unroll
-                    for (int k = 0; k < RT; k++) {
-                        if (64 * k >= T) continue;                          // wave-uniform
-                        const int e = Eb[desc[k] & 0xffff], m = Mb[desc[k] >> 16];
-                        const int d4 = ((vmask >> k) & 1) ? 320 - 16 * e : -(1 << 20);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) acc[B][c] += L.bitlut[lut_index(d4, m, so[c])];
-                    }
+                        if (B >= b0 && B < b1) { acc[B][0] += sum[0]; acc[B][1] += sum[1]; acc[B][2] += sum[2]; }
+                    r = rn;
+                    ev = evn;
                 }
             }
             int total[3] = {0, 0, 0};
@@ -1052,7 +1010,7 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                 const bool is_lfe = P.lfe && ch == nch - 1;
                 const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
                 const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
-                const uint8_t *e = L.E[b * 6 + ch];
+                const uint8_t *e = ex + ((size_t)b * nch + ch) * 256;
                 put(4, e[0]);
                 for (int g = lane; g < ng; g += 64) {
                     const int k0 = 1 + 3 * g * gs;
@@ -1075,40 +1033,49 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
 
             // ---- mantissas (:1334-1502): one sweep, 64 consecutive coefficients per step.  Two packed
             //      wavefront scans per step give every coefficient its rank among the 3/5/11-level codes
-            //      and its bit offset.  A grouped code is assembled in L.gtab (ring of 128 slots per kind,
+            //      and its bit offset.  A grouped code is assembled in L.gtab (rings of 32 / 32 / 64 slots,
             //      only the newest group of a kind can be incomplete): the opener stores offset and its
             //      weighted value, later members add theirs, the last member writes the code out. ----
             if (P.tap_bap) {
                 uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
-                uint8_t *te = P.tap_eexp + (fidx * 6 + b) * nch * 256;
                 for (int ch = 0; ch < nch; ch++)
                     for (int i = lane; i < 256; i += 64) {
                         const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
                         if (i >= n) tb[ch * 256 + i] = 0;
-                        te[ch * 256 + i] = L.E[b * 6 + ch][i];
                     }
             }
             {
-                const uint8_t *Eb = &L.E[b * 6][0];
+                const uint8_t *Eb = ex + (size_t)b * nch * 256;
                 const int16_t *Mb = &L.mask[b * 6][0];
                 const int32_t *mdb = md + (size_t)b * nch * 256;
-                // all of the block's coefficients in flight before the first step (the fences below would
-                // otherwise expose one HBM round trip per step)
-                int coef[RT];
-#pragma unroll
-                for (int k = 0; k < RT; k++) coef[k] = 64 * k < T ? mdb[desc[k] & 0xffff] : 0;
+                // step k covers coefficients 64k .. 64k+63 of the block's stream (channel-major, LFE last); the
+                // coefficient and exponent of the next step are already in flight while this one is packed
+                const int R = (T + 63) >> 6;
+                int t_ch = lane / nbc, t_bin = lane - t_ch * nbc;           // lane < 64 <= nbc: channel 0
+                if (nfbw == 0) { t_ch = 0; t_bin = lane; }
+                int nx_coef = lane < T ? mdb[t_ch * 256 + t_bin] : 0;
+                int nx_exp = lane < T ? Eb[t_ch * 256 + t_bin] : 0;
                 int b3 = 0, b5 = 0, b11 = 0;
-#pragma unroll
-                for (int k = 0; k < RT; k++) {
-                    if (64 * k >= T) continue;                              // wave-uniform
-                    const int eo = desc[k] & 0xffff;
-                    const bool valid = (vmask >> k) & 1;
-                    const int ex = Eb[eo], m = Mb[desc[k] >> 16];
-                    const int d4 = valid ? 320 - 16 * ex : -(1 << 20);
+#pragma unroll 1
+                for (int k = 0; k < R; k++) {
+                    const int eo = t_ch * 256 + t_bin;
+                    const bool valid = 64 * k + lane < T;
+                    const int c = nx_coef, xe = nx_exp;
+                    const int m = Mb[t_ch * 50 + L.band_of_bin[t_bin]];
+                    // next step's position and loads
+                    t_bin += 64;
+                    if (t_ch < nfbw && t_bin >= nbc) { t_bin -= nbc; t_ch++; }
+                    {
+                        const bool nv = 64 * (k + 1) + lane < T;
+                        const int no = nv ? t_ch * 256 + t_bin : 0;
+                        nx_coef = mdb[no];
+                        nx_exp = Eb[no];
+                        if (!nv) { t_ch = 0; t_bin = 0; }
+                    }
+                    const int d4 = valid ? 320 - 16 * xe : -(1 << 20);
                     const uint32_t lut = L.bitlut[lut_index(d4, m, snroffset)];
                     const int bp = (int)(lut >> 28);
-                    const int c = coef[k];
-                    const int e = ex - (int)L.shiftv[b * 6 + (eo >> 8)];
+                    const int e = xe - (int)L.shiftv[b * 6 + (eo >> 8)];
                     if (P.tap_bap && valid) P.tap_bap[(fidx * 6 + b) * nch * 256 + eo] = (uint8_t)bp;
 
                     const int kind = bp == 1 ? 0 : bp == 2 ? 1 : bp == 4 ? 2 : -1;
@@ -1136,7 +1103,8 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                     const int v = sym ? quant_sym(c, e, levels) : quant_asym(c, e, w ? w : 1);
                     if (!grouped) put_bits(L.fr, off, w, (uint32_t)v);
 
-                    uint32_t *slot = &L.gtab[kind < 0 ? 0 : kind][grp & 127];
+                    // a step opens at most 22 / 22 / 32 groups and one older group per kind can be incomplete
+                    uint32_t *slot = kind == 2 ? &L.gtab[64 + (grp & 63)] : &L.gtab[(kind == 1 ? 32 : 0) + (grp & 31)];
                     const int wgt = mem == per - 1 ? 1 : mem == 0 ? (kind == 2 ? 11 : levels * levels) : levels;
                     if (opens) *slot = (off << 8) | (uint32_t)(v * wgt);
                     WAVE_SYNC();
@@ -1150,9 +1118,9 @@ __global__ __launch_bounds__(64, 2) void enc_pack_kernel(const PackParams P)
                 // a trailing group that never got its last member is written as it stands
                 WAVE_SYNC();
                 if (lane == 0) {
-                    if (b3 % 3) { const uint32_t x = L.gtab[0][(b3 / 3) & 127]; put_bits(L.fr, x >> 8, 5, x & 0xff); }
-                    if (b5 % 3) { const uint32_t x = L.gtab[1][(b5 / 3) & 127]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
-                    if (b11 & 1) { const uint32_t x = L.gtab[2][(b11 >> 1) & 127]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
+                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(L.fr, x >> 8, 5, x & 0xff); }
+                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
+                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
                 }
             }
             WAVE_SYNC();
