@@ -86,23 +86,30 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
     sn[lane] = P.tab->sin[lane];
 
     const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
+    // samples lane, 64+lane, 128+lane, 192+lane of: the block before (history), this block, and - in flight while
+    // this block is transformed - the next one.  Every sample is read from HBM once.
+    int16_t oldv[4], newv[4], nxtv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + 64 * k;
+        if (f > 0) oldv[k] = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];         // block 5 of the previous frame
+        else oldv[k] = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
+        newv[k] = frame_pcm[(size_t)j * P.nch];
+    }
     for (int blk = 0; blk < 6; blk++) {
         // ---- 512 input samples: 256 old + 256 new (:1673-1683) ----
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = lane + 64 * k;
-            int16_t oldv;
-            if (blk > 0) oldv = frame_pcm[(size_t)((blk - 1) * 256 + j) * P.nch];
-            else if (f > 0) oldv = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];      // block 5 of the previous frame
-            else oldv = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
-            const int16_t newv = frame_pcm[(size_t)(blk * 256 + j) * P.nch];
+            nxtv[k] = blk < 5 ? frame_pcm[(size_t)((blk + 1) * 256 + j) * P.nch] : (int16_t)0;
             if (P.store_history && blk == 5) {
-                if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv;
-                else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv;
+                if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
+                else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
             }
             // window (:1686-1693)
-            in[j] = (int16_t)((oldv * win[j]) >> 15);
-            in[256 + j] = (int16_t)((newv * win[255 - j]) >> 15);
+            in[j] = (int16_t)((oldv[k] * win[j]) >> 15);
+            in[256 + j] = (int16_t)((newv[k] * win[255 - j]) >> 15);
+            oldv[k] = newv[k];
         }
         WAVE_SYNC();
         // ---- block floating point (:1697-1700) ----
@@ -198,6 +205,8 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
         *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
         *reinterpret_cast<uint32_t *>(P.expo + row * 256 + 4 * lane) = epack;
         if (lane == 0) P.shift[row] = (int8_t)shift;
+#pragma unroll
+        for (int k = 0; k < 4; k++) newv[k] = nxtv[k];
         WAVE_SYNC();
     }
 }
