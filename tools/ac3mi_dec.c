@@ -4,11 +4,13 @@
  *   a52dec-0.7.5-cvs/src/a52dec.c:130-238 (usage, handle_args), :240-310 (a52_decode_data), :600-640 (es_loop)
  *   a52dec-0.7.5-cvs/libao/audio_out_wav.c:60-213 (wav / wavdolby / wav6), audio_out_float.c, audio_out_null.c,
  *   a52dec-0.7.5-cvs/libao/convert2s16.c:33-41, 199-306 (convert2s16_wav)
- * restricted to elementary streams (the -s/-t/-T demultiplexers are SURVEY 8f rank 4), so that whole files can
- * be compared against the upstream tool.  Written against include/ac3mi_dropin.h (liba52's API): the program is
+ * so that whole files can be compared against the upstream tool, plus its three demultiplexers:
+ *   a52dec.c:312-540 (demux: MPEG-1/2 program streams, private stream 1 sub-stream 0x80+track; PES-only mode),
+ *   a52dec.c:554-592 (ts_loop: 188-byte transport packets of one PID carrying that PES).  Written against include/ac3mi_dropin.h (liba52's API): the program is
  * plain C and knows nothing about the GPU.
  *
- *   ac3mi_dec [-o wav|wavdolby|wav6|float|null|null4|null6] [-r] [-a] [-g <gain dB>] [-c] [<file>]  > out
+ *   ac3mi_dec [-o wav|wavdolby|wav6|float|null|null4|null6] [-s [<track>]] [-t <pid>] [-T] [-r] [-a] [-g <gain dB>]
+ *             [-c] [<file>]  > out
  */
 #include <errno.h>
 #include <math.h>
@@ -166,8 +168,11 @@ static void output_close(void)
 
 static void usage(const char *argv0)
 {
-    fprintf(stderr, "usage: %s [-h] [-o <mode>] [-c] [-r] [-a] [-g <gain>] <file>\n"
+    fprintf(stderr, "usage: %s [-h] [-o <mode>] [-s [<track>]] [-t <pid>] [-T] [-c] [-r] [-a] [-g <gain>] <file>\n"
                     "\t-h\tdisplay help and available audio output modes\n"
+                    "\t-s\tuse program stream demultiplexer, track 0-7 or 0x80-0x87\n"
+                    "\t-t\tuse transport stream demultiplexer, pid 0x10-0x1ffe\n"
+                    "\t-T\tuse transport stream PES demultiplexer\n"
                     "\t-c\taccepted for compatibility (no accelerations to disable)\n"
                     "\t-r\tdisable dynamic range compression\n"
                     "\t-a\tdisable level adjustment based on output mode\n"
@@ -177,14 +182,187 @@ static void usage(const char *argv0)
     exit(1);
 }
 
+/* ---- elementary-stream framing, push model ----
+ * a52dec's behaviour (a52dec.c:240-310): a frame starts wherever a52_syncinfo accepts seven bytes; a position it
+ * rejects is skipped byte by byte ("skip" on stderr per byte); a frame that fails to set up or decode costs one
+ * "error" and the stream resumes after it. */
+static a52_state_t *state;
+static uint8_t es_win[2 * 3840 + 4096];
+static size_t es_have;
+
+static void es_drain(void)
+{
+    size_t at = 0;
+    while (es_have - at >= 7) {
+        int flags, sample_rate, bit_rate;
+        const int length = a52_syncinfo(es_win + at, &flags, &sample_rate, &bit_rate);
+        if (!length) { fprintf(stderr, "skip\n"); at++; continue; }
+        if (es_have - at < (size_t)length) break;           /* wait for the rest of the frame */
+        float level, bias;
+        int done = 0;
+        if (!output_setup(sample_rate, &flags, &level, &bias)) {
+            if (!disable_adjust) flags |= A52_ADJUST_LEVEL;
+            level = (float)(level * gain);
+            if (!a52_frame(state, es_win + at, &flags, &level, bias)) {
+                if (disable_dynrng) a52_dynrng(state, NULL, NULL);
+                while (done < 6 && !a52_block(state) && !output_play(flags, a52_samples(state))) done++;
+            }
+        }
+        if (done != 6) fprintf(stderr, "error\n");
+        at += (size_t)length;
+    }
+    memmove(es_win, es_win + at, es_have - at);
+    es_have -= at;
+}
+
+static void es_push(const uint8_t *p, size_t n)
+{
+    while (n) {
+        size_t room = sizeof es_win - es_have, take = n < room ? n : room;
+        memcpy(es_win + es_have, p, take);
+        es_have += take;
+        p += take;
+        n -= take;
+        es_drain();
+    }
+}
+
+/* ---- MPEG system layers (ISO 11172-1 / 13818-1), as far as a52dec looks at them ----
+ * All three demultiplexers work on a byte queue: packets are parsed once they are complete. */
+static uint8_t *q_buf;
+static size_t q_len, q_cap;
+
+static void q_append(const uint8_t *p, size_t n)
+{
+    if (q_len + n > q_cap) {
+        q_cap = 2 * (q_len + n) + 65536;
+        q_buf = realloc(q_buf, q_cap);
+        if (!q_buf) { fprintf(stderr, "out of memory\n"); exit(1); }
+    }
+    memcpy(q_buf + q_len, p, n);
+    q_len += n;
+}
+static void q_drop(size_t n) { memmove(q_buf, q_buf + n, q_len - n); q_len -= n; }
+
+/* length of the PES header that ends right before the payload, for a private-stream-1 packet at p (p[3] == 0xbd);
+ * 0 = need more bytes (have = bytes available) */
+static size_t pes_header_len(const uint8_t *p, size_t have)
+{
+    if (have < 7) return 0;
+    if ((p[6] & 0xc0) == 0x80) {                            /* MPEG-2: flags, flags, header_data_length */
+        if (have < 9) return 0;
+        return 9 + (size_t)p[8];
+    }
+    size_t len = 6;                                         /* MPEG-1: stuffing, STD buffer, PTS/DTS */
+    int stuffing = 0;
+    while (1) {
+        if (have <= len) return 0;
+        if (p[len] != 0xff) break;
+        len++;
+        if (++stuffing == 17) { fprintf(stderr, "too much stuffing\n"); break; }
+    }
+    if ((p[len] & 0xc0) == 0x40) { len += 2; if (have <= len) return 0; }
+    static const int skip[16] = {0, 0, 4, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return len + (size_t)skip[p[len] >> 4] + 1;
+}
+
+/* program stream (track >= 0x80: private stream 1 sub-stream `track`) or bare PES stream of 0xbd packets (track < 0).
+ * Returns 1 at a program end code. */
+static int ps_parse(int track, int at_eof)
+{
+    for (;;) {
+        size_t i = 0;
+        while (i + 4 <= q_len && !(q_buf[i] == 0 && q_buf[i + 1] == 0 && q_buf[i + 2] == 1)) i++;
+        if (i) q_drop(i);
+        if (q_len < 4) return 0;
+        const uint8_t *p = q_buf;
+        const int id = p[3];
+        size_t total;
+        if (track < 0 && id != 0xbd) { fprintf(stderr, "bad stream id %x\n", id); exit(1); }
+        if (id == 0xb9 && track >= 0) return 1;
+        if (id == 0xba) {                                   /* pack header */
+            if (q_len < 5) return 0;
+            if ((p[4] & 0xc0) == 0x40) { if (q_len < 14) return 0; total = 14 + (size_t)(p[13] & 7); }
+            else if ((p[4] & 0xf0) == 0x20) total = 12;
+            else { fprintf(stderr, "weird pack header\n"); total = 5; }
+            if (q_len < total) return 0;
+            q_drop(total);
+            continue;
+        }
+        if (id < 0xb9) { fprintf(stderr, "looks like a video stream, not system stream\n"); exit(1); }
+        if (q_len < 6) return 0;
+        total = 6 + (((size_t)p[4] << 8) | p[5]);
+        if (q_len < total) {
+            if (!at_eof) return 0;
+            total = q_len;                                  /* truncated last packet: use what is there */
+        }
+        if (id == 0xbd) {
+            size_t hl = pes_header_len(p, total);
+            if (track < 0 && hl && (p[6] & 0xc0) != 0x80) { fprintf(stderr, "bad multiplex - not mpeg2\n"); exit(1); }
+            if (hl && hl < total) {
+                if (track < 0) es_push(p + hl, total - hl);
+                else if (p[hl] == track && hl + 4 <= total) es_push(p + hl + 4, total - hl - 4);   /* id, count, pointer */
+            }
+        }
+        q_drop(total);
+        if (at_eof && q_len < 4) return 0;
+    }
+}
+
+static void run_ps(FILE *in, int track)
+{
+    static uint8_t chunk[4096];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof chunk, in)) > 0) {
+        q_append(chunk, got);
+        if (ps_parse(track, 0)) return;
+    }
+    ps_parse(track, 1);
+}
+
+/* transport stream: the payloads of one PID form a PES stream of private-stream-1 packets (a52dec.c:554-592) */
+static void run_ts(FILE *in, int pid)
+{
+    static uint8_t buf[188 * 64];
+    size_t have = 0, got;
+    int in_payload = 0;                                     /* inside a PES packet's data */
+    while ((got = fread(buf + have, 1, sizeof buf - have, in)) > 0 || have >= 188) {
+        have += got;
+        size_t at = 0;
+        while (at + 188 <= have) {
+            const uint8_t *t = buf + at;
+            if (t[0] != 0x47) { fprintf(stderr, "bad sync byte\n"); at++; continue; }
+            at += 188;
+            if ((((t[1] << 8) | t[2]) & 0x1fff) != pid) continue;
+            const uint8_t *data = t + 4;
+            if (t[3] & 0x20) { data = t + 5 + t[4]; if (data > t + 188) continue; }
+            if (!(t[3] & 0x10)) continue;
+            size_t n = (size_t)(t + 188 - data);
+            if (t[1] & 0x40) {                              /* payload_unit_start: a PES header comes first */
+                if (n < 9 || data[0] || data[1] || data[2] != 1) { in_payload = 0; continue; }
+                if (data[3] != 0xbd) { fprintf(stderr, "bad stream id %x\n", data[3]); exit(1); }
+                if ((data[6] & 0xc0) != 0x80) { fprintf(stderr, "bad multiplex - not mpeg2\n"); exit(1); }
+                const size_t hl = 9 + (size_t)data[8];
+                in_payload = 1;
+                if (hl < n) es_push(data + hl, n - hl);
+            } else if (in_payload) {
+                es_push(data, n);
+            }
+        }
+        memmove(buf, buf + at, have - at);
+        have -= at;
+        if (got == 0) break;
+    }
+}
+
 int main(int argc, char **argv)
 {
     static const struct { const char *name; int kind, flags; } modes[] = {
         {"wav", OUT_WAV, A52_STEREO}, {"wavdolby", OUT_WAV, A52_DOLBY}, {"wav6", OUT_WAV, -1}, {"null", OUT_NULL, A52_STEREO},
         {"null4", OUT_NULL, A52_2F2R}, {"null6", OUT_NULL, A52_3F2R | A52_LFE}, {"float", OUT_FLOAT, A52_STEREO}};
-    int c;
+    int c, demux_track = 0, demux_pid = 0, demux_pes = 0;
     char *s;
-    while ((c = getopt(argc, argv, "hcrag:o:")) != -1) switch (c) {
+    while ((c = getopt(argc, argv, "hs::t:Tcrag:o:")) != -1) switch (c) {
         case 'o': {
             int found = 0;
             for (size_t i = 0; i < sizeof modes / sizeof modes[0]; i++)
@@ -192,6 +370,19 @@ int main(int argc, char **argv)
             if (!found) { fprintf(stderr, "Invalid video driver: %s\n", optarg); usage(argv[0]); }
             break;
         }
+        case 's':
+            demux_track = 0x80;
+            if (optarg) {
+                demux_track = (int)strtol(optarg, &s, 0);
+                if (demux_track < 0x80) demux_track += 0x80;
+                if (demux_track < 0x80 || demux_track > 0x87 || *s) { fprintf(stderr, "Invalid track number: %s\n", optarg); usage(argv[0]); }
+            }
+            break;
+        case 't':
+            demux_pid = (int)strtol(optarg, &s, 0);
+            if (demux_pid < 0x10 || demux_pid > 0x1ffe || *s) { fprintf(stderr, "Invalid pid: %s\n", optarg); usage(argv[0]); }
+            break;
+        case 'T': demux_pes = 1; break;
         case 'c': break;
         case 'r': disable_dynrng = 1; break;
         case 'a': disable_adjust = 1; break;
@@ -207,42 +398,16 @@ int main(int argc, char **argv)
         fprintf(stderr, "%s - could not open file %s\n", strerror(errno), argv[optind]);
         return 1;
     }
-    a52_state_t *state = a52_init(0);
+    state = a52_init(0);
     if (!state) { fprintf(stderr, "A52 init failed\n"); return 1; }
 
-    /* Elementary-stream framing with a52dec's behaviour (a52dec.c:240-310): a frame starts wherever a52_syncinfo
-     * accepts seven bytes; a position it rejects is skipped byte by byte ("skip" on stderr per byte); a frame that
-     * fails to set up or decode costs one "error" and the stream resumes after it. */
-    static uint8_t win[2 * 3840 + 4096];
-    size_t have = 0, at = 0;
-    int eof = 0;
-    for (;;) {
-        if (have - at < 3840 && !eof) {                 /* top the window up so that any frame fits */
-            memmove(win, win + at, have - at);
-            have -= at;
-            at = 0;
-            const size_t got = fread(win + have, 1, sizeof win - have, in_file);
-            have += got;
-            eof = got == 0;
-            if (!eof) continue;
-        }
-        if (have - at < 7) break;
-        int flags, sample_rate, bit_rate;
-        const int length = a52_syncinfo(win + at, &flags, &sample_rate, &bit_rate);
-        if (!length) { fprintf(stderr, "skip\n"); at++; continue; }
-        if (have - at < (size_t)length) break;          /* truncated last frame */
-        float level, bias;
-        int done = 0;
-        if (!output_setup(sample_rate, &flags, &level, &bias)) {
-            if (!disable_adjust) flags |= A52_ADJUST_LEVEL;
-            level = (float)(level * gain);
-            if (!a52_frame(state, win + at, &flags, &level, bias)) {
-                if (disable_dynrng) a52_dynrng(state, NULL, NULL);
-                while (done < 6 && !a52_block(state) && !output_play(flags, a52_samples(state))) done++;
-            }
-        }
-        if (done != 6) fprintf(stderr, "error\n");
-        at += (size_t)length;
+    if (demux_pid) run_ts(in_file, demux_pid);
+    else if (demux_track) run_ps(in_file, demux_track);
+    else if (demux_pes) run_ps(in_file, -1);
+    else {
+        static uint8_t chunk[4096];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, in_file)) > 0) es_push(chunk, got);
     }
     output_close();
     a52_free(state);
