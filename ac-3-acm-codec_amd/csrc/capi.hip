@@ -70,6 +70,23 @@ void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
     for (int i = 0; i < 7; i++) t->qlev[8 + i] = q(2 * (i - 3), 7);
     for (int i = 0; i < 11; i++) t->qlev[16 + i] = q(2 * (i - 5), 11);
     for (int i = 0; i < 15; i++) t->qlev[27 + i] = q(2 * (i - 7), 15);
+    memset(t->qtab, 0, sizeof t->qtab);
+    for (int code = 0; code < 27; code++) {
+        t->qtab[code * 3 + 0] = t->qlev[code / 9];
+        t->qtab[code * 3 + 1] = t->qlev[(code / 3) % 3];
+        t->qtab[code * 3 + 2] = t->qlev[code % 3];
+    }
+    for (int code = 0; code < 125; code++) {
+        t->qtab[96 + code * 3 + 0] = t->qlev[3 + code / 25];
+        t->qtab[96 + code * 3 + 1] = t->qlev[3 + (code / 5) % 5];
+        t->qtab[96 + code * 3 + 2] = t->qlev[3 + code % 5];
+    }
+    for (int code = 0; code < 121; code++) {
+        t->qtab[480 + code * 2 + 0] = t->qlev[16 + code / 11];
+        t->qtab[480 + code * 2 + 1] = t->qlev[16 + code % 11];
+    }
+    for (int code = 0; code < 7; code++) t->qtab[736 + code] = t->qlev[8 + code];
+    for (int code = 0; code < 15; code++) t->qtab[744 + code] = t->qlev[27 + code];
     // dither generator (L52/parse.c:310-319, table L52/tables.h:213-246): one call advances a
     // 16-bit Galois LFSR (feedback 0xa011) by 8 steps.  It is GF(2)-linear with period 65535,
     // so the sequence from state 1 plus its inverse index give O(1) access to any later draw.

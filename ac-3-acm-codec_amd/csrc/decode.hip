@@ -44,6 +44,7 @@ struct DecLDS {
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
     uint8_t gcode[3][128];                // open 3/5/11-level codes, indexed by group number mod 128
+    float qtab[760];                      // dequantised code members (DecTables::qtab)
     uint8_t cplbnd[20];                   // coupling sub-band -> band
     int16_t seg_base[9];                  // mantissa stream segments
     uint8_t seg_ch[8], seg_start[8];
@@ -346,17 +347,6 @@ __device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int s
 // ---------------------------------------------------------------------------
 // mantissa helpers
 
-// Symmetric n-level dequantiser (n = 3, 5, 7, 11, 15; L52/parse.c:272-308 q_1..q_5): level idx is
-// round(32768 * (2*idx - (n-1)) / n).  The product below is within 0.01 of that quotient, whose
-// fractional part is at least 1/(2n) away from one half, so the rounding reproduces the table.
-__device__ __forceinline__ float level_value(int idx, int n, float scale)
-{
-    return __builtin_rintf((float)(2 * idx - (n - 1)) * scale);
-}
-
-// exact a / d for 0 <= a < 128, 1 <= d <= 25 (d given as 1.0f/d)
-__device__ __forceinline__ int small_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
-
 __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t idx0, int k)
 {
     // k-th draw (k = 0 first) = state after k+1 steps
@@ -382,6 +372,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     if (lane < 50) L.hth[lane] = 0;
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
+    for (int i = lane; i < 760; i += 64) L.qtab[i] = P.tab->qtab[i];
     for (int i = lane; i < 256; i += 64) {
         int b = i < 20 ? i : 20;
         if (i >= 20) while (b < 49 && i >= P.tab->band_end[b - 20]) b++;
@@ -800,7 +791,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                                        : kind == 1 ? b5 + (int)((gexcl >> 8) & 255u)
                                                    : b11 + (int)(gexcl >> 16);
                         const int per = kind == 2 ? 2 : 3;
-                        const int grp = rank / per, mem = rank - grp * per;
+                        const int grp = kind == 2 ? rank >> 1 : (int)(((uint32_t)rank * 0xaaabu) >> 17);      // rank / 3, rank < 2^15
+                        const int mem = rank - grp * per;
                         const bool opens = kind >= 0 && mem == 0;
                         const int nb = w > 0 ? w : opens ? (kind == 0 ? 5 : 7) : 0;
                         const int nd = w == 0 ? draws : 0;
@@ -817,27 +809,17 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-                        // levels: 3/5/11-level codes hold 3/3/2 base-n digits; bap 3 and 4 are 7 and 15 levels
+                        // 3/5/11-level codes (3/3/2 members) and the 7- and 15-level codes of bap 3 and 4 through one
+                        // table (reserved codes read 0); wider mantissas are two's complement fractions
                         float q = 0.f;
                         {
-                            const int n = kind == 0 ? 3 : kind == 1 ? 5 : kind == 2 ? 11 : w == 3 ? 7 : 15;
-                            const float scale = kind == 0 ? 32768.f / 3 : kind == 1 ? 32768.f / 5 : kind == 2 ? 32768.f / 11
-                                              : w == 3 ? 32768.f / 7 : 32768.f / 15;
-                            int idx = (int)raw;
-                            bool valid = true;
-                            if (kind >= 0) {
-                                const int code = L.gcode[kind][grp & 127];
-                                const float invn = kind == 0 ? 1.f / 3 : kind == 1 ? 1.f / 5 : 1.f / 11;
-                                // digit `mem` of the code: (code / n^(per-1-mem)) % n
-                                const int up = per - 1 - mem;
-                                const float invd = up == 0 ? 1.f : up == 1 ? invn : (kind == 0 ? 1.f / 9 : 1.f / 25);
-                                const int t = small_div(code, invd);
-                                idx = t - n * small_div(t, invn);
-                                valid = code < (kind == 0 ? 27 : kind == 1 ? 125 : 121);
-                            }
-                            else valid = idx < n;                          // 3- and 4-bit codes 7 and 15 decode to 0
-                            if (kind >= 0 || w == 3 || w == 4) q = valid ? level_value(idx, n, scale) : 0.f;
-                            else if (w > 0) q = (float)((((int32_t)(raw << (32 - w))) >> (32 - w)) * (1 << (16 - w)));
+                            const bool coded = kind >= 0 || w == 3 || w == 4;
+                            const int code = kind >= 0 ? (int)L.gcode[kind][grp & 127] : (int)raw;
+                            const int base = kind == 0 ? 0 : kind == 1 ? 96 : kind == 2 ? 480 : w == 3 ? 736 : 744;
+                            const int ti = base + code * (kind >= 0 ? per : 1) + (kind >= 0 ? mem : 0);
+                            const float tv = L.qtab[coded ? ti : 0];
+                            const float pv = (float)((((int32_t)(raw << ((32 - w) & 31))) >> ((32 - w) & 31)) * (1 << ((16 - w) & 31)));
+                            q = coded ? tv : w > 0 ? pv : 0.f;
                         }
 
                         if (ch < 6) {
