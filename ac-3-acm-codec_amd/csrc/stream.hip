@@ -108,6 +108,7 @@ struct ac3mi_pool {
     ac3mi_ctx *ctx;
     int capacity;
     std::vector<int> free_slots;
+    std::vector<char> dirty;        // slot state differs from a fresh a52_init / AC3_encode_init
     // per-slot carry-over state (device)
     float *d_delay;         // [cap][6][128]
     uint16_t *d_lfsr;       // [cap]
@@ -434,6 +435,7 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
     p->ctx = ctx;
     p->capacity = capacity;
     for (int i = capacity - 1; i >= 0; i--) p->free_slots.push_back(i);
+    p->dirty.assign((size_t)capacity, 0);
     const size_t n = (size_t)capacity;
     bool ok = true;
     auto dev = [&](size_t bytes) -> void * { void *q = ac3mi_dev_alloc(ctx, bytes); ok = ok && q; return q; };
@@ -451,6 +453,15 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
     p->h_frames = (uint8_t *)pin(n * FRAME_STRIDE);
     p->h_s16 = (int16_t *)pin(n * PCM_FRAME_BYTES);
     p->h_status = (uint32_t *)pin(n * 4);
+    if (ok) {
+        // every slot starts as a52_init (delay 0, lfsr 1, L52/parse.c:75) and AC3_encode_init (history 0, csnroffst 40,
+        // ENC/ac3enc.cpp:1092) leave a new stream
+        std::vector<uint16_t> ones(n, 1);
+        std::vector<int32_t> forty(n, 40);
+        ok = ac3mi_memset(ctx, p->d_delay, 0, n * 6 * 128 * 4) == AC3MI_OK && ac3mi_memset(ctx, p->d_last, 0, n * 6 * 256 * 2) == AC3MI_OK &&
+             ac3mi_memcpy_h2d(ctx, p->d_lfsr, ones.data(), n * 2) == AC3MI_OK &&
+             ac3mi_memcpy_h2d(ctx, p->d_csnr, forty.data(), n * 4) == AC3MI_OK && ac3mi_sync(ctx) == AC3MI_OK;
+    }
     if (!ok) { ac3mi_pool_destroy(p); return nullptr; }
     return p;
 }
@@ -560,20 +571,23 @@ int ac3mi_stream_open(ac3mi_pool *pool, const ac3mi_wavefmt *src, const ac3mi_wa
     bool ok = true;
     if (decode) {
         st->framelen = ac3mi_stream_framesize(src);
-        const uint16_t one = 1;                                     // a52_init: lfsr_state = 1, delay = 0
-        ok = ok && ac3mi_memset(ctx, pool->d_delay + (size_t)st->slot * 6 * 128, 0, 6 * 128 * 4) == AC3MI_OK;
-        ok = ok && ac3mi_memcpy_h2d(ctx, pool->d_lfsr + st->slot, &one, 2) == AC3MI_OK;
     } else {
         st->enc_cfg = cfg;
         st->enc_rate = (int)src->samples_per_sec;
         st->enc_bitrate = kbps * 1000;
         ac3mi_encode_desc d = {st->enc_rate, st->enc_bitrate, src->channels};
         st->framelen = ac3mi_encode_frame_bytes(&d);                // msd->framelen = AC3_encode_init(...)
-        const int32_t c40 = 40;                                     // ENC/ac3enc.cpp:1092
+    }
+    if (pool->dirty[(size_t)st->slot]) {                            // a slot another stream has used
+        const uint16_t one = 1;
+        const int32_t c40 = 40;
+        ok = ok && ac3mi_memset(ctx, pool->d_delay + (size_t)st->slot * 6 * 128, 0, 6 * 128 * 4) == AC3MI_OK;
+        ok = ok && ac3mi_memcpy_h2d(ctx, pool->d_lfsr + st->slot, &one, 2) == AC3MI_OK;
         ok = ok && ac3mi_memset(ctx, pool->d_last + (size_t)st->slot * 6 * 256, 0, 6 * 256 * 2) == AC3MI_OK;
         ok = ok && ac3mi_memcpy_h2d(ctx, pool->d_csnr + st->slot, &c40, 4) == AC3MI_OK;
+        ok = ok && ac3mi_sync(ctx) == AC3MI_OK;
     }
-    ok = ok && ac3mi_sync(ctx) == AC3MI_OK;
+    pool->dirty[(size_t)st->slot] = 1;
     if (!ok) { pool->free_slots.push_back(st->slot); delete st; return AC3MI_MMSYSERR_NOMEM; }
     *out = st;
     return AC3MI_MMSYSERR_NOERROR;

@@ -242,3 +242,21 @@ def test_open_rules_and_sizes(S, pool):
     rc, s_ = pool.open(ac3, S.pcm_format(2, 48000))
     assert rc == 0
     s_.close()
+
+
+def test_slot_reuse_starts_clean(S, pool):
+    """a closed stream's state slot goes to the next open, which must find a52_init's state in it"""
+    fmt = (S.ac3_format(6, 48000, 384, block_align=1536), S.pcm_format(6, 48000))
+    for seed in (301, 302):
+        frames = H.orc_encode(H.gen_pcm(3, 6, seed=seed, kind="quiet" if seed == 302 else "tones"))   # quiet: dither state shows
+        rc, st = pool.open(*fmt)
+        assert rc == 0
+        data = frames.tobytes()
+        src = np.frombuffer(data, np.uint8).copy()
+        dst = np.zeros(3 * 6 * 256 * 12, np.uint8)
+        h = S.StreamHeader(src.ctypes.data, src.size, 0, dst.ctypes.data, dst.size, 0, S.STREAMCONVERTF_START)
+        assert st.convert(h) == 0 and h.src_used == src.size and h.dst_used == dst.size
+        want = _oracle_s16(frames, 7 | 16).reshape(-1).astype(np.int32)
+        got = np.frombuffer(dst.tobytes(), np.int16).astype(np.int32)
+        assert int(np.abs(got - want).max()) <= 1
+        st.close()
