@@ -31,12 +31,7 @@ namespace ac3mi {
 
 __device__ __forceinline__ int ilog2u(unsigned v) { return v ? 31 - __builtin_clz(v) : 0; }   // av_log2, :1539-1567
 
-__device__ __forceinline__ int wave_or(int v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
-    return v;
-}
+__device__ __forceinline__ int wave_or(int v) { return (int)wave_or_u32((uint32_t)v); }
 __device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint32_t)v); }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,18 @@ __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__b
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last(wave_incl_scan_u32(v)); }
 
+// bitwise OR of all lanes, wave-uniform
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return wave_last(v);
+}
+
 // prefix minimum / maximum (lanes shifted in from outside a row keep the identity)
 __device__ __forceinline__ int wave_incl_scan_min(int v)
 {
