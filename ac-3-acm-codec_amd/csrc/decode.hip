@@ -80,18 +80,34 @@ __device__ __forceinline__ int32_t speek(const FrameBits fr, uint32_t pos, int n
 struct Rd {                                   // wave-uniform serial reader
     FrameBits fr;
     uint32_t pos;
+    // 64-bit window of the bits at `wpos` (scalar registers): one LDS read per ~32 bits instead of one per field
+    uint32_t wpos;
+    uint64_t win;
+    int avail;
+    __device__ __forceinline__ void prime()
+    {
+        uint32_t w = pos >> 5;
+        w = w < fr.last ? w : fr.last;
+        const uint32_t hi = rfl(fr.w[w]), lo = rfl(fr.w[w + 1]);
+        win = (((uint64_t)hi << 32) | lo) << (pos & 31);
+        avail = 64 - (int)(pos & 31);
+        wpos = pos;
+    }
     __device__ __forceinline__ uint32_t get(int n)
     {
         if (n == 0) return 0;
-        uint32_t v = rfl(peek(fr, pos, n));
+        if (pos != wpos || avail < n) prime();
+        const uint32_t v = (uint32_t)(win >> (64 - n));
+        win <<= n;
+        avail -= n;
         pos += n;
+        wpos = pos;
         return v;
     }
     __device__ __forceinline__ int32_t sget(int n)
     {
-        int32_t v = (int32_t)rfl((uint32_t)speek(fr, pos, n));
-        pos += n;
-        return v;
+        const uint32_t v = get(n);
+        return ((int32_t)(v << (32 - n))) >> (32 - n);
     }
 };
 
@@ -425,7 +441,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        Rd rd{FB, 0};
+        Rd rd{FB, 0, ~0u, 0, 0};
         // ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205) ----
         bool hdr_ok = true;
         {
