@@ -13,6 +13,7 @@ struct DecTables {
     uint16_t hth[3][50];
     int8_t width[64];
     uint8_t band_end[30];
+    uint8_t band_of_bin[256];   // band of a bin (bins 0..27 are their own band)
     float qlev[48];     // [0,3) 3-level  [3,8) 5-level  [8,16) 7-level  [16,27) 11-level  [27,43) 15-level
     // dequantised value of member m of a code: 3-level [code*3+m] at 0 (32 codes), 5-level at 96 (128 codes),
     // 11-level [code*2+m] at 480 (128 codes), 7-level [code] at 736, 15-level [code] at 744; reserved codes give 0

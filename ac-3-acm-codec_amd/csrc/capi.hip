@@ -59,6 +59,11 @@ void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
     memcpy(t->hth, kHth, sizeof t->hth);
     memcpy(t->width, kWidth, sizeof t->width);
     memcpy(t->band_end, kBandEnd, sizeof t->band_end);
+    for (int i = 0; i < 256; i++) {
+        int b = i < 20 ? i : 20;
+        while (i >= 20 && b < 49 && i >= kBandEnd[b - 20]) b++;
+        t->band_of_bin[i] = (uint8_t)b;
+    }
     // Q(x) = ROUND(32768 x) for the symmetric quantiser levels (L52/tables.h:49)
     auto q = [](int num, int den) {
         double x = 32768.0 * num / den;

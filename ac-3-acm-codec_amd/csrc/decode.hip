@@ -389,11 +389,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
     for (int i = lane; i < 760; i += 64) L.qtab[i] = P.tab->qtab[i];
-    for (int i = lane; i < 256; i += 64) {
-        int b = i < 20 ? i : 20;
-        if (i >= 20) while (b < 49 && i >= P.tab->band_end[b - 20]) b++;
-        L.band_of_bin[i] = (uint8_t)b;
-    }
+    for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
     for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
     for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
