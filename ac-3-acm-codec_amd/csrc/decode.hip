@@ -7,16 +7,16 @@
 //
 // One wavefront (= one 64-thread workgroup) owns one stream and walks its frames in
 // order, because the dither LFSR and the exponent / bit-allocation state carry over.
-//  * the frame is staged once into LDS as byte-swapped dwords; every bit field is then a
-//    2-dword LDS read + funnel shift
-//  * side information is serial: it is parsed redundantly by all lanes on wave-uniform
-//    values (scalar-unit work)
-//  * exponents: one lane per 7-bit group, wavefront prefix sum of the deltas
-//  * bit allocation: one lane per channel runs the band recurrences
-//  * mantissas: every lane takes a contiguous run of the block's coefficient stream;
-//    two wavefront scans give the bit offset and the grouped-code rank of every
-//    coefficient, a third gives the dither draw index (the LFSR is GF(2)-linear, so the
-//    k-th draw is a table lookup: lfsr_seq[(lfsr_idx[state] + k) mod 65535])
+//  * the frame is staged once into (dynamic) LDS as byte-swapped dwords
+//  * side information is serial: parsed by all lanes on wave-uniform values through a 64-bit
+//    scalar bit window (struct Rd)
+//  * exponents: one lane per 7-bit group, DPP prefix sum of the deltas
+//  * bit allocation: the whole wavefront per channel (bit_allocate_wave): one lane per band for
+//    the PSD integration, lowcomp as an automaton evaluated by scans, leaks as prefix minima
+//  * mantissas: one sweep, 64 consecutive coefficients of a channel segment per step; two packed
+//    DPP scans give grouped-code ranks, bit offsets and dither draw indices (the LFSR is
+//    GF(2)-linear, so the k-th draw is a table lookup: lfsr_seq[(lfsr_idx[state] + k) mod 65535]);
+//    dequantisation through one LDS table; planes go straight to HBM
 //
 // Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
 #include "ac3mi_internal.h"

@@ -1,19 +1,22 @@
 // encode.hip — AC-3 encoder on gfx950, bit-exact restatement of ENC/ac3enc.cpp
-// (AC3_encode_frame, :1640-1763) in two kernels.
+// (AC3_encode_frame, :1640-1763) in three kernels.
 //
 //  enc_mdct_kernel   one wavefront per (stream, frame, channel): gather/deinterleave via chmap,
 //                    Q15 window, block-floating-point normalisation, the reference's 16-bit
 //                    radix-2 DIT FFT (one butterfly per lane per pass, data in LDS so that every
 //                    butterfly has exactly the reference's operands, shifts and int16 stores),
 //                    post-rotation, exponent extraction.            [ac3enc.cpp:1665-1722, 462-603]
+//  enc_exp_kernel    one wavefront per (stream, frame, channel): exponent strategy, min-merge over
+//                    reuse runs, the +-2 constraint in closed form (min over j of g[j] + 2|i-j| as a
+//                    prefix and a suffix minimum), band PSDs and masking curves of the blocks that
+//                    send exponents.                                          [ac3enc.cpp:606-761, 220-367]
 //  enc_pack_kernel   one wavefront per stream, frames in order (the SNR-offset search starts from
-//                    the previous frame's csnroffst): exponent strategy, min-merge and constraint
-//                    (closed form: min over j of g[j] + 2|i-j|), PSD/excitation/mask once per
-//                    (block, channel) on one lane each, the reference's exact search sequence with
-//                    every candidate evaluated by a wavefront-wide histogram reduction,
-//                    quantisation, grouped-mantissa assembly with LDS atomics, bit packing with
-//                    prefix-summed offsets, both CRCs by per-lane chunk CRC + GF(2) combine.
-//                                                                      [ac3enc.cpp:606-975, 1113-1638]
+//                    the previous frame's csnroffst): the reference's exact search sequence with
+//                    memoised verdicts and up to three offsets costed per sweep (one LUT read per
+//                    coefficient and offset, every run of exponent reuse counted once), quantisation,
+//                    grouped-mantissa assembly with LDS atomics, bit packing with prefix-summed
+//                    offsets, both CRCs by per-lane chunk CRC + GF(2) combine.
+//                                                                      [ac3enc.cpp:764-975, 1113-1638]
 //
 // Integer arithmetic only (no -ffast-math dependence); the Q15 tables come from the host (capi.hip)
 // with the reference's expressions.
