@@ -714,7 +714,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
         ctx->ws_enc_bytes = need;
     }
     E.ws_mdct = (int32_t *)ctx->ws_enc;
-    E.ws_expo = (uint8_t *)ctx->ws_enc + off_expo;
+    E.ws_expo = nullptr;                                                   // raw exponents leave the MDCT kernel only as a tap
     E.ws_eexp = (uint8_t *)ctx->ws_enc + off_eexp;
     E.ws_emask = (int16_t *)((uint8_t *)ctx->ws_enc + off_emask);
     E.ws_shift = (int8_t *)ctx->ws_enc + off_shift;

@@ -1,12 +1,12 @@
 // encode.hip — AC-3 encoder on gfx950, bit-exact restatement of ENC/ac3enc.cpp
-// (AC3_encode_frame, :1640-1763) in three kernels.
+// (AC3_encode_frame, :1640-1763) in two kernels.
 //
 //  enc_mdct_kernel   one wavefront per (stream, frame, channel): gather/deinterleave via chmap,
 //                    Q15 window, block-floating-point normalisation, the reference's 16-bit
 //                    radix-2 DIT FFT (one butterfly per lane per pass, data in LDS so that every
 //                    butterfly has exactly the reference's operands, shifts and int16 stores),
-//                    post-rotation, exponent extraction.            [ac3enc.cpp:1665-1722, 462-603]
-//  enc_exp_kernel    one wavefront per (stream, frame, channel): exponent strategy, min-merge over
+//                    post-rotation, exponent extraction             [ac3enc.cpp:1665-1722, 462-603];
+//                    then, still per channel (exp_stage): exponent strategy, min-merge over
 //                    reuse runs, the +-2 constraint in closed form (min over j of g[j] + 2|i-j| as a
 //                    prefix and a suffix minimum), band PSDs and masking curves of the blocks that
 //                    send exponents.                                          [ac3enc.cpp:606-761, 220-367]
@@ -36,178 +36,6 @@ __device__ __forceinline__ int ilog2u(unsigned v) { return v ? 31 - __builtin_cl
 
 __device__ __forceinline__ int wave_or(int v) { return (int)wave_or_u32((uint32_t)v); }
 __device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint32_t)v); }
-
-// ---------------------------------------------------------------------------------------------
-// kernel 1: window + normalise + MDCT + exponents
-
-struct MdctParams {
-    const int16_t *pcm;         // [S][F][1536][nch] interleaved
-    int16_t *last;              // [S][nch][256] history before frame 0 (rewritten here when store_history)
-    int32_t *mdct;              // [S][F][6][nch][256]
-    uint8_t *expo;              // [S][F][6][nch][256]
-    int8_t *shift;              // [S][F][6][nch]
-    const EncTables *tab;
-    int n_streams, frames, nch;
-    uint8_t chmap[8];
-    const int32_t *slot;        // optional: stream s keeps its history in slot[s] (stride 6*256 samples)
-    int store_history;          // one frame per stream: this kernel also leaves the new history (else enc_history_kernel)
-};
-
-struct c16 { int16_t re, im; };
-
-__device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int ay)
-{
-    p.re = (int16_t)((bx + ax) >> 1);
-    p.im = (int16_t)((by + ay) >> 1);
-    q.re = (int16_t)((bx - ax) >> 1);
-    q.im = (int16_t)((by - ay) >> 1);
-}
-
-__global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
-{
-    __shared__ int16_t in[512];
-    __shared__ c16 z[128];
-    __shared__ int32_t out[256];
-    __shared__ int16_t win[256], xc[128], xs[128], ct[64], sn[64];
-    __shared__ uint8_t rev[128];
-
-    const int lane = threadIdx.x;
-    const int unit = blockIdx.x;                    // (s*F + f)*nch + ch
-    const int ch = unit % P.nch;
-    const int sf = unit / P.nch;
-    const int f = sf % P.frames;
-    const int s = sf / P.frames;
-
-    for (int i = lane; i < 256; i += 64) win[i] = P.tab->win[i];
-    for (int i = lane; i < 128; i += 64) { xc[i] = P.tab->xcos[i]; xs[i] = P.tab->xsin[i]; rev[i] = P.tab->bitrev[i]; }
-    ct[lane] = P.tab->cos[lane];
-    sn[lane] = P.tab->sin[lane];
-
-    const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
-    // samples lane, 64+lane, 128+lane, 192+lane of: the block before (history), this block, and - in flight while
-    // this block is transformed - the next one.  Every sample is read from HBM once.
-    int16_t oldv[4], newv[4], nxtv[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int j = lane + 64 * k;
-        if (f > 0) oldv[k] = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];         // block 5 of the previous frame
-        else oldv[k] = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
-        newv[k] = frame_pcm[(size_t)j * P.nch];
-    }
-    for (int blk = 0; blk < 6; blk++) {
-        // ---- 512 input samples: 256 old + 256 new (:1673-1683) ----
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = lane + 64 * k;
-            nxtv[k] = blk < 5 ? frame_pcm[(size_t)((blk + 1) * 256 + j) * P.nch] : (int16_t)0;
-            if (P.store_history && blk == 5) {
-                if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
-                else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
-            }
-            // window (:1686-1693)
-            in[j] = (int16_t)((oldv[k] * win[j]) >> 15);
-            in[256 + j] = (int16_t)((newv[k] * win[255 - j]) >> 15);
-            oldv[k] = newv[k];
-        }
-        WAVE_SYNC();
-        // ---- block floating point (:1697-1700) ----
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int v = in[lane + 64 * k];
-            acc |= v < 0 ? -v : v;
-        }
-        acc = wave_or(acc);
-        int v = 14 - ilog2u((unsigned)acc);
-        if (v < 0) v = 0;
-        const int shift = v - 9;
-        if (v > 0) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(in[lane + 64 * k] * (1 << v));
-        }
-        WAVE_SYNC();
-        // ---- rotation + pre-rotation (:578-591), stored bit-reversed (:496-504) ----
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = lane + 64 * k;
-            auto rot = [&](int t) -> int { return t < 128 ? (int)(int16_t)(-in[t + 384]) : (int)in[t - 128]; };
-            const int re = (rot(2 * i) - rot(511 - 2 * i)) >> 1;
-            const int im = (-(rot(256 + 2 * i) - rot(255 - 2 * i))) >> 1;
-            const int c = -xc[i], sx = xs[i];
-            c16 t;
-            t.re = (int16_t)((re * c - im * sx) >> 15);
-            t.im = (int16_t)((re * sx + c * im) >> 15);
-            z[rev[i]] = t;
-        }
-        WAVE_SYNC();
-        // ---- pass 0 (:508-515) ----
-        {
-            c16 p = z[2 * lane], q = z[2 * lane + 1];
-            bfly(p, q, p.re, p.im, q.re, q.im);
-            z[2 * lane] = p;
-            z[2 * lane + 1] = q;
-        }
-        WAVE_SYNC();
-        // ---- pass 1 (:519-529): twiddles 1 and -j ----
-        {
-            const int base = 4 * (lane >> 1) + (lane & 1);
-            c16 p = z[base], q = z[base + 2];
-            if (lane & 1) bfly(p, q, p.re, p.im, q.im, -q.re);
-            else bfly(p, q, p.re, p.im, q.re, q.im);
-            z[base] = p;
-            z[base + 2] = q;
-        }
-        WAVE_SYNC();
-        // ---- passes 2..6 (:533-567) ----
-        for (int nloops = 4, nblocks = 16; nblocks; nloops <<= 1, nblocks >>= 1) {
-            const int j = lane / nloops, m = lane - j * nloops;
-            const int ip = j * 2 * nloops + m, iq = ip + nloops;
-            c16 p = z[ip], q = z[iq];
-            if (m == 0) bfly(p, q, p.re, p.im, q.re, q.im);
-            else {
-                const int l = m * nblocks;
-                const int c = ct[l], sx = -sn[l];
-                const int tr = (c * q.re - sx * q.im) >> 15;
-                const int ti = (c * q.im + q.re * sx) >> 15;
-                bfly(p, q, p.re, p.im, tr, ti);
-            }
-            z[ip] = p;
-            z[iq] = q;
-            WAVE_SYNC();
-        }
-        // ---- post-rotation (:596-602) ----
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = lane + 64 * k;
-            const int re = z[i].re, im = z[i].im, sx = xs[i], c = xc[i];
-            out[2 * i] = (re * c + sx * im) >> 15;
-            out[255 - 2 * i] = (re * sx - im * c) >> 15;
-        }
-        WAVE_SYNC();
-        // ---- exponents (:1707-1722) ----
-        const size_t row = (((size_t)s * P.frames + f) * 6 + blk) * P.nch + ch;
-        int4 cv = *reinterpret_cast<const int4 *>(&out[4 * lane]);
-        int cc[4] = {cv.x, cv.y, cv.z, cv.w};
-        uint32_t epack = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int a = cc[k] < 0 ? -cc[k] : cc[k];
-            int e;
-            if (a == 0) e = 24;
-            else {
-                e = 23 - ilog2u((unsigned)a) + shift;
-                if (e >= 24) { e = 24; cc[k] = 0; }
-            }
-            epack |= (uint32_t)(e & 0xff) << (8 * k);
-        }
-        *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
-        *reinterpret_cast<uint32_t *>(P.expo + row * 256 + 4 * lane) = epack;
-        if (lane == 0) P.shift[row] = (int8_t)shift;
-#pragma unroll
-        for (int k = 0; k < 4; k++) newv[k] = nxtv[k];
-        WAVE_SYNC();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // kernel 2: exponent coding, bit allocation, quantisation, packing
@@ -422,7 +250,7 @@ __device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wavefront-wide versions of the two routines above for enc_exp_kernel (same results).
+// Wavefront-wide versions of the two routines above for exp_stage (same results).
 
 // encode_exp on one row: entry i = 1 + 64c + lane of chunk c.  min over j of g[j] + 2|i-j| is a prefix minimum of
 // g[j] - 2j (ascending) followed by a suffix minimum of g[j] + 2j (descending).
@@ -516,12 +344,12 @@ __device__ void mask_row_wave(const MaskTabs &T, int16_t *bndpsd, int bndend, bo
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 1b: exponent strategy, min-merge, constraint and masking curves.  Everything here is
-// independent per channel, so one wavefront takes the six blocks of one (stream, frame, channel).
+// second half of kernel 1: exponent strategy, min-merge, constraint and masking curves.  Everything here is
+// independent per channel, like the MDCT: the wavefront that transformed the six blocks of one
+// (stream, frame, channel) goes straight on with their exponents.
 
 struct ExpParams {
-    const uint8_t *expo;        // [S][F][6][nch][256] raw exponents (enc_mdct_kernel)
-    uint8_t *eexp;              // same shape, encoded
+    uint8_t *eexp;              // [S][F][6][nch][256] encoded exponents
     int16_t *emask;             // [S][F][6][nch][50]
     uint8_t *strat;             // [S][F][6][nch]
     int32_t *ebits;             // [S][F][nch]
@@ -536,30 +364,15 @@ struct ExpLDS {
     uint8_t strat[8];
 };
 
-__global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
+// Runs at the end of enc_mdct_kernel: L.t holds the tables, L.E the six blocks' raw exponents of this channel.
+__device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, int lane)
 {
-    __shared__ ExpLDS L;
-    const int lane = threadIdx.x;
     const int nch = P.nch;
-    const size_t fidx = blockIdx.x / nch;
-    const int ch = blockIdx.x - (int)fidx * nch;
     const bool is_lfe = P.lfe && ch == nch - 1;
     const int n = is_lfe ? 7 : P.nbc;
-
-    for (int i = lane; i < 256; i += 64) {
-        L.t.latab[i] = P.tab->latab[i];
-        L.t.band_of_bin[i] = P.tab->band_of_bin[i];
-    }
-    if (lane < 50) L.t.hth[lane] = P.tab->hth[lane][P.fscod];
-    if (lane < 52) L.t.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0;
-
-    // ---- raw exponents, four bins per lane ----
     uint32_t raw[6];
 #pragma unroll
-    for (int b = 0; b < 6; b++) {
-        raw[b] = *reinterpret_cast<const uint32_t *>(P.expo + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane);
-        *reinterpret_cast<uint32_t *>(&L.E[b][4 * lane]) = raw[b];
-    }
+    for (int b = 0; b < 6; b++) raw[b] = *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
 
     // ---- exponent strategy (:617-669): sum of |differences| over all 256 bins against the block before ----
     int st[6];
@@ -619,20 +432,24 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
     //      reuses them has the same curve.  Bands 0..27 are single bins; the 22 wider ones are integrated by
     //      one lane each, two rows per sweep ----
     {
-        int rows[6], nrows = 0, src_of[6];
+        uint32_t starts = 0;                                        // bit b: block b sends exponents (wave-uniform)
 #pragma unroll
-        for (int b = 0; b < 6; b++) {
-            if (st[b] != 0) rows[nrows++] = b;                      // st[] is wave-uniform
-            src_of[b] = rows[nrows - 1];                            // block 0 always sends
-        }
+        for (int b = 0; b < 6; b++) starts |= (st[b] != 0 ? 1u : 0u) << b;
         const int nsingle = n < 28 ? n : 28;
-        for (int i = 0; i < nrows; i++)
-            if (lane < nsingle) L.mask[rows[i]][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[rows[i]][lane] << 7));
+        for (uint32_t m = starts; m; m &= m - 1) {
+            const int r = __builtin_ctz(m);
+            if (lane < nsingle) L.mask[r][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[r][lane] << 7));
+        }
         if (n > 28) {
-            for (int p = 0; 2 * p < nrows; p++) {
+            for (uint32_t m = starts; m;) {
+                const int ra = __builtin_ctz(m);
+                m &= m - 1;
+                const bool two = m != 0;
+                const int rb = two ? __builtin_ctz(m) : ra;
+                m &= m - 1;
                 const int half = lane >> 5, band = 28 + (lane & 31);
-                const int r = rows[2 * p + half < nrows ? 2 * p + half : 2 * p];
-                const bool active = (lane & 31) < 22 && 2 * p + half < nrows;
+                const int r = half ? rb : ra;
+                const bool active = (lane & 31) < 22 && (half == 0 || two);
                 const int start = L.t.band_start[active ? band : 28];
                 int end1 = L.t.band_start[active ? band + 1 : 29];
                 end1 = end1 < n ? end1 : n;
@@ -657,12 +474,13 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
         const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
         const int sgain = 0x4d8, dbknee = 0x900, fgain = 128 * (fgaincod + 1);
         const int bndend = L.t.band_of_bin[n - 1] + 1;
-        for (int i = 0; i < nrows; i++)
-            mask_row_wave(L.t, L.mask[rows[i]], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
+        for (uint32_t m = starts; m; m &= m - 1)
+            mask_row_wave(L.t, L.mask[__builtin_ctz(m)], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
         WAVE_SYNC();
-#pragma unroll
-        for (int b = 1; b < 6; b++)
-            if (src_of[b] != b && lane < 50) L.mask[b][lane] = L.mask[src_of[b]][lane];
+        for (int b = 1, src = 0; b < 6; b++) {
+            if ((starts >> b) & 1) { src = b; continue; }
+            if (lane < 50) L.mask[b][lane] = L.mask[src][lane];
+        }
     }
     WAVE_SYNC();
 
@@ -678,6 +496,189 @@ __global__ __launch_bounds__(64) void enc_exp_kernel(const ExpParams P)
     if (lane < 6) P.strat[(fidx * 6 + lane) * nch + ch] = L.strat[lane];
     if (lane == 0) P.ebits[fidx * nch + ch] = exp_bits;
 }
+
+// ---------------------------------------------------------------------------------------------
+// kernel 1: window + normalise + MDCT + exponents
+
+struct MdctParams {
+    const int16_t *pcm;         // [S][F][1536][nch] interleaved
+    int16_t *last;              // [S][nch][256] history before frame 0 (rewritten here when store_history)
+    int32_t *mdct;              // [S][F][6][nch][256]
+    uint8_t *expo;              // [S][F][6][nch][256]
+    int8_t *shift;              // [S][F][6][nch]
+    const EncTables *tab;
+    int n_streams, frames, nch;
+    uint8_t chmap[8];
+    const int32_t *slot;        // optional: stream s keeps its history in slot[s] (stride 6*256 samples)
+    int store_history;          // one frame per stream: this kernel also leaves the new history (else enc_history_kernel)
+    ExpParams x;                // the exponent stage that follows the transform
+};
+
+struct c16 { int16_t re, im; };
+
+__device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int ay)
+{
+    p.re = (int16_t)((bx + ax) >> 1);
+    p.im = (int16_t)((by + ay) >> 1);
+    q.re = (int16_t)((bx - ax) >> 1);
+    q.im = (int16_t)((by - ay) >> 1);
+}
+
+__global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
+{
+    __shared__ int16_t in[512];
+    __shared__ c16 z[128];
+    __shared__ int32_t out[256];
+    __shared__ int16_t win[256], xc[128], xs[128], ct[64], sn[64];
+    __shared__ uint8_t rev[128];
+    __shared__ ExpLDS XL;
+
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;                    // (s*F + f)*nch + ch
+    const int ch = unit % P.nch;
+    const int sf = unit / P.nch;
+    const int f = sf % P.frames;
+    const int s = sf / P.frames;
+
+    for (int i = lane; i < 256; i += 64) win[i] = P.tab->win[i];
+    for (int i = lane; i < 128; i += 64) { xc[i] = P.tab->xcos[i]; xs[i] = P.tab->xsin[i]; rev[i] = P.tab->bitrev[i]; }
+    ct[lane] = P.tab->cos[lane];
+    sn[lane] = P.tab->sin[lane];
+    for (int i = lane; i < 256; i += 64) {
+        XL.t.latab[i] = P.tab->latab[i];
+        XL.t.band_of_bin[i] = P.tab->band_of_bin[i];
+    }
+    if (lane < 50) XL.t.hth[lane] = P.tab->hth[lane][P.x.fscod];
+    if (lane < 52) XL.t.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0;
+
+    const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
+    // samples lane, 64+lane, 128+lane, 192+lane of: the block before (history), this block, and - in flight while
+    // this block is transformed - the next one.  Every sample is read from HBM once.
+    int16_t oldv[4], newv[4], nxtv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + 64 * k;
+        if (f > 0) oldv[k] = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];         // block 5 of the previous frame
+        else oldv[k] = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
+        newv[k] = frame_pcm[(size_t)j * P.nch];
+    }
+    for (int blk = 0; blk < 6; blk++) {
+        // ---- 512 input samples: 256 old + 256 new (:1673-1683) ----
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            nxtv[k] = blk < 5 ? frame_pcm[(size_t)((blk + 1) * 256 + j) * P.nch] : (int16_t)0;
+            if (P.store_history && blk == 5) {
+                if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
+                else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
+            }
+            // window (:1686-1693)
+            in[j] = (int16_t)((oldv[k] * win[j]) >> 15);
+            in[256 + j] = (int16_t)((newv[k] * win[255 - j]) >> 15);
+            oldv[k] = newv[k];
+        }
+        WAVE_SYNC();
+        // ---- block floating point (:1697-1700) ----
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = in[lane + 64 * k];
+            acc |= v < 0 ? -v : v;
+        }
+        acc = wave_or(acc);
+        int v = 14 - ilog2u((unsigned)acc);
+        if (v < 0) v = 0;
+        const int shift = v - 9;
+        if (v > 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(in[lane + 64 * k] * (1 << v));
+        }
+        WAVE_SYNC();
+        // ---- rotation + pre-rotation (:578-591), stored bit-reversed (:496-504) ----
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = lane + 64 * k;
+            auto rot = [&](int t) -> int { return t < 128 ? (int)(int16_t)(-in[t + 384]) : (int)in[t - 128]; };
+            const int re = (rot(2 * i) - rot(511 - 2 * i)) >> 1;
+            const int im = (-(rot(256 + 2 * i) - rot(255 - 2 * i))) >> 1;
+            const int c = -xc[i], sx = xs[i];
+            c16 t;
+            t.re = (int16_t)((re * c - im * sx) >> 15);
+            t.im = (int16_t)((re * sx + c * im) >> 15);
+            z[rev[i]] = t;
+        }
+        WAVE_SYNC();
+        // ---- pass 0 (:508-515) ----
+        {
+            c16 p = z[2 * lane], q = z[2 * lane + 1];
+            bfly(p, q, p.re, p.im, q.re, q.im);
+            z[2 * lane] = p;
+            z[2 * lane + 1] = q;
+        }
+        WAVE_SYNC();
+        // ---- pass 1 (:519-529): twiddles 1 and -j ----
+        {
+            const int base = 4 * (lane >> 1) + (lane & 1);
+            c16 p = z[base], q = z[base + 2];
+            if (lane & 1) bfly(p, q, p.re, p.im, q.im, -q.re);
+            else bfly(p, q, p.re, p.im, q.re, q.im);
+            z[base] = p;
+            z[base + 2] = q;
+        }
+        WAVE_SYNC();
+        // ---- passes 2..6 (:533-567) ----
+        for (int nloops = 4, nblocks = 16; nblocks; nloops <<= 1, nblocks >>= 1) {
+            const int j = lane / nloops, m = lane - j * nloops;
+            const int ip = j * 2 * nloops + m, iq = ip + nloops;
+            c16 p = z[ip], q = z[iq];
+            if (m == 0) bfly(p, q, p.re, p.im, q.re, q.im);
+            else {
+                const int l = m * nblocks;
+                const int c = ct[l], sx = -sn[l];
+                const int tr = (c * q.re - sx * q.im) >> 15;
+                const int ti = (c * q.im + q.re * sx) >> 15;
+                bfly(p, q, p.re, p.im, tr, ti);
+            }
+            z[ip] = p;
+            z[iq] = q;
+            WAVE_SYNC();
+        }
+        // ---- post-rotation (:596-602) ----
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = lane + 64 * k;
+            const int re = z[i].re, im = z[i].im, sx = xs[i], c = xc[i];
+            out[2 * i] = (re * c + sx * im) >> 15;
+            out[255 - 2 * i] = (re * sx - im * c) >> 15;
+        }
+        WAVE_SYNC();
+        // ---- exponents (:1707-1722) ----
+        const size_t row = (((size_t)s * P.frames + f) * 6 + blk) * P.nch + ch;
+        int4 cv = *reinterpret_cast<const int4 *>(&out[4 * lane]);
+        int cc[4] = {cv.x, cv.y, cv.z, cv.w};
+        uint32_t epack = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = cc[k] < 0 ? -cc[k] : cc[k];
+            int e;
+            if (a == 0) e = 24;
+            else {
+                e = 23 - ilog2u((unsigned)a) + shift;
+                if (e >= 24) { e = 24; cc[k] = 0; }
+            }
+            epack |= (uint32_t)(e & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
+        if (P.expo) *reinterpret_cast<uint32_t *>(P.expo + row * 256 + 4 * lane) = epack;       // tap only
+        *reinterpret_cast<uint32_t *>(&XL.E[blk][4 * lane]) = epack;
+        if (lane == 0) P.shift[row] = (int8_t)shift;
+#pragma unroll
+        for (int k = 0; k < 4; k++) newv[k] = nxtv[k];
+        WAVE_SYNC();
+    }
+    exp_stage(P.x, XL, (size_t)sf, ch, lane);
+}
+
 
 // bap of one coefficient for SNR offset `snroffset` (:393-420):
 //   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
@@ -1200,25 +1201,19 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     M.nch = c.nch;
     for (int i = 0; i < 8; i++) M.chmap[i] = E.chmap[i];
     M.slot = E.slot;
-    M.store_history = E.frames_per_stream == 1;      // the only reader of last[] is this same wavefront's block 0
+    M.store_history = E.frames_per_stream == 1;
+    M.x.eexp = E.ws_eexp;
+    M.x.emask = E.ws_emask;
+    M.x.strat = E.ws_strat;
+    M.x.ebits = E.ws_ebits;
+    M.x.tab = tab.enc;
+    M.x.nch = c.nch;
+    M.x.lfe = c.lfe;
+    M.x.fscod = c.fscod;
+    M.x.halfrate = c.halfrate;
+    M.x.nbc = 223;      // the only reader of last[] is this same wavefront's block 0
     hipLaunchKernelGGL(enc_mdct_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, M);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-
-    ExpParams X;
-    X.expo = E.ws_expo;
-    X.eexp = E.ws_eexp;
-    X.emask = E.ws_emask;
-    X.strat = E.ws_strat;
-    X.ebits = E.ws_ebits;
-    X.tab = tab.enc;
-    X.nch = c.nch;
-    X.lfe = c.lfe;
-    X.fscod = c.fscod;
-    X.halfrate = c.halfrate;
-    X.nbc = 223;
-    hipLaunchKernelGGL(enc_exp_kernel, dim3(E.n_streams * E.frames_per_stream * c.nch), dim3(64), 0, stream, X);
-    e = hipGetLastError();
     if (e != hipSuccess) return e;
 
     PackParams P;
