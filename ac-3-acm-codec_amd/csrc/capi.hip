@@ -723,7 +723,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     if (taps && taps->d_mdct) E.ws_mdct = taps->d_mdct;
     if (taps && taps->d_exponent) E.ws_expo = taps->d_exponent;
     if (taps && taps->d_exp_samples) E.ws_shift = taps->d_exp_samples;
-    if (taps && taps->d_encoded_exp) E.ws_eexp = taps->d_encoded_exp;      // enc_exp_kernel writes the tap directly
+    if (taps && taps->d_encoded_exp) E.ws_eexp = taps->d_encoded_exp;      // the exponent stage writes the tap directly
     E.pcm = d_pcm;
     E.last = d_last;
     E.csnr = d_csnroffst;

@@ -42,7 +42,7 @@ __device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint3
 
 struct PackParams {
     const int32_t *mdct;
-    const uint8_t *eexp;        // [S][F][6][nch][256] encoded exponents   (enc_exp_kernel)
+    const uint8_t *eexp;        // [S][F][6][nch][256] encoded exponents   (exp_stage)
     const int16_t *emask;       // [S][F][6][nch][50]  masking curve minus the floor
     const uint8_t *strat;       // [S][F][6][nch]
     const int32_t *ebits;       // [S][F][nch] bits of the coded exponents
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
-        // ---- masking curves, strategies and exponent bit counts from enc_exp_kernel (the encoded exponents
+        // ---- masking curves, strategies and exponent bit counts from exp_stage (the encoded exponents
         //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
         const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
         {
