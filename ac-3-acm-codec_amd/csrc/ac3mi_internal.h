@@ -126,6 +126,9 @@ struct ac3mi_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
+    // second stream for the transform of a large decode batch: it overlaps the next chunk's front end
+    hipStream_t stream2;
+    hipEvent_t ev_chunk[4], ev_join;
     ac3mi::DeviceTables tab;
     // decode workspace (coefficient planes + block-switch flags between the two kernels)
     float *ws_coef;

@@ -337,6 +337,9 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     std::vector<float> win(256);
     std::vector<float2> twl(128), tws(128);
     build_host_tables(win.data(), twl.data(), tws.data());
@@ -412,6 +415,9 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_chunk[i]);
+    (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -620,36 +626,56 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     if (!coef) coef = ctx->ws_coef;
     if (!blksw) blksw = ctx->ws_blksw;
 
-    DecodeLaunch D;
-    D.frames = d_frames;
-    D.frame_bytes = desc->frame_bytes;
-    D.frame_stride = frame_stride;
-    D.n_streams = n_streams;
-    D.frames_per_stream = frames_per_stream;
-    D.req_flags = desc->flags;
-    D.acmod = desc->acmod;
-    D.lfeon = desc->lfeon ? 1 : 0;
-    D.dynrng_on = desc->dynrng ? 1 : 0;
-    D.level = desc->level;
-    D.coef = coef;
-    D.blksw = blksw;
-    D.status = d_status;
-    D.lfsr = d_lfsr;
-    D.slot = ctx->slots;
-    D.tap_exp = taps ? taps->d_exp : nullptr;
-    D.tap_bap = taps ? taps->d_bap : nullptr;
-    HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
+    // A large batch goes through in four chunks of streams: the (HBM-bound) transform of chunk i runs on a
+    // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 4 : 1;       // measured: 4.79 -> 4.66 ms on 65536 frames
+    const size_t F = (size_t)frames_per_stream;
+    for (int k = 0; k < n_chunks; k++) {
+        const int s0 = (int)((long long)n_streams * k / n_chunks), s1 = (int)((long long)n_streams * (k + 1) / n_chunks);
+        const int ns = s1 - s0;
+        if (ns <= 0) continue;
+        const size_t f0 = (size_t)s0 * F;
+        DecodeLaunch D;
+        D.frames = d_frames + f0 * frame_stride;
+        D.frame_bytes = desc->frame_bytes;
+        D.frame_stride = frame_stride;
+        D.n_streams = ns;
+        D.frames_per_stream = frames_per_stream;
+        D.req_flags = desc->flags;
+        D.acmod = desc->acmod;
+        D.lfeon = desc->lfeon ? 1 : 0;
+        D.dynrng_on = desc->dynrng ? 1 : 0;
+        D.level = desc->level;
+        D.coef = coef + f0 * 6 * X.plan.n_in * 256;
+        D.blksw = blksw + f0 * 6 * X.plan.nfchans;
+        D.status = d_status + f0;
+        D.lfsr = ctx->slots ? d_lfsr : d_lfsr + s0;
+        D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
+        D.tap_exp = taps && taps->d_exp ? taps->d_exp + f0 * 6 * 7 * 256 : nullptr;
+        D.tap_bap = taps && taps->d_bap ? taps->d_bap + f0 * 6 * 7 * 256 : nullptr;
+        HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
 
-    X.coef = coef;
-    X.blksw = blksw;
-    X.delay = d_delay;
-    X.slot = ctx->slots;
-    X.delay_stride = 6 * 128;
-    X.pcm = d_pcm;
-    X.n_streams = n_streams;
-    X.frames = frames_per_stream;
-    X.bias = desc->bias;
-    HIPCHK(ctx, launch_xform(ctx->tab, X, ctx->stream));
+        hipStream_t xs = ctx->stream;
+        if (n_chunks > 1) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_chunk[k], ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_chunk[k], 0));
+            xs = ctx->stream2;
+        }
+        X.coef = D.coef;
+        X.blksw = D.blksw;
+        X.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * X.plan.n_out * 128;
+        X.slot = D.slot;
+        X.delay_stride = 6 * 128;
+        X.pcm = d_pcm + f0 * 6 * X.plan.n_out * 256;
+        X.n_streams = ns;
+        X.frames = frames_per_stream;
+        X.bias = desc->bias;
+        HIPCHK(ctx, launch_xform(ctx->tab, X, xs));
+    }
+    if (n_chunks > 1) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
     return AC3MI_OK;
 }
 
