@@ -128,7 +128,7 @@ struct ac3mi_ctx {
     hipEvent_t ev0, ev1;
     // second stream for the transform of a large decode batch: it overlaps the next chunk's front end
     hipStream_t stream2;
-    hipEvent_t ev_chunk[4], ev_join;
+    hipEvent_t ev_chunk[4], ev_mid[4], ev_join;
     ac3mi::DeviceTables tab;
     // decode workspace (coefficient planes + block-switch flags between the two kernels)
     float *ws_coef;
@@ -137,6 +137,9 @@ struct ac3mi_ctx {
     // encode workspace (MDCT coefficients, exponents, block exponents between the two kernels)
     void *ws_enc;
     size_t ws_enc_bytes;
+    // transcode workspace (float PCM and s16 PCM between the decoder and the encoder)
+    void *ws_tc;
+    size_t ws_tc_bytes;
     // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
     const int32_t *slots;
     std::string err;

@@ -339,6 +339,7 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_mid[i], hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     std::vector<float> win(256);
     std::vector<float2> twl(128), tws(128);
@@ -386,6 +387,8 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->tab = DeviceTables{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ctx->ws_enc = nullptr;
     ctx->ws_enc_bytes = 0;
+    ctx->ws_tc = nullptr;
+    ctx->ws_tc_bytes = 0;
     ctx->slots = nullptr;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
@@ -412,10 +415,12 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->ws_coef);
     (void)hipFree(ctx->ws_blksw);
     (void)hipFree(ctx->ws_enc);
+    (void)hipFree(ctx->ws_tc);
     (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_chunk[i]);
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_mid[i]);
     (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -767,6 +772,157 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
         return AC3MI_ERR_ARG;
     }
     HIPCHK(ctx, launch_encode(ctx->tab, E, ctx->stream));
+    return AC3MI_OK;
+}
+
+int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac3mi_encode_desc *enc,
+                          const uint8_t *d_frames_in, int in_stride, int n_streams, int frames_per_stream,
+                          float *d_delay, uint16_t *d_lfsr, const uint8_t *chmap, int16_t *d_last,
+                          int32_t *d_csnroffst, uint8_t *d_frames_out, int out_stride, uint32_t *d_status)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    if (!dec || !enc || !d_frames_in || !d_delay || !d_lfsr || !chmap || !d_last || !d_csnroffst || !d_frames_out || !d_status ||
+        n_streams < 0 || frames_per_stream < 0 || dec->frame_bytes < 8 || dec->frame_bytes > 3840 ||
+        in_stride < ((dec->frame_bytes + 3) & ~3) || (in_stride & 3) || ((uintptr_t)d_frames_in & 3)) {
+        ctx->err = "ac3mi_transcode_batch: bad argument";
+        return AC3MI_ERR_ARG;
+    }
+    ac3mi_decode_desc dd = *dec;
+    dd.level = 1.0f;                                    // the s16 converter reads the 16-bit value out of the float (bias 384)
+    dd.bias = 384.0f;
+    int n_out = 0, out_flags = 0;
+    XformLaunch X;
+    if (ac3mi_decode_planes(&dd, &n_out, &out_flags) != AC3MI_OK || build_mix_plan(dd.acmod, dd.lfeon, out_flags, &X.plan) != AC3MI_OK) {
+        ctx->err = "ac3mi_transcode_batch: requested output not supported (a52_frame would return 1)";
+        return AC3MI_ERR_ARG;
+    }
+    EncodeLaunch E;
+    const int fb = enc_config(enc->sample_rate, enc->bit_rate, enc->channels, &E.cfg);
+    if (fb <= 0 || enc->channels != n_out) {
+        ctx->err = "ac3mi_transcode_batch: encoder configuration rejected, or its channel count differs from the decoder's output";
+        return AC3MI_ERR_ARG;
+    }
+    if (out_stride < ((fb + 3) & ~3) || (out_stride & 3) || ((uintptr_t)d_frames_out & 3)) {
+        ctx->err = "ac3mi_transcode_batch: out_stride must be a multiple of 4 and >= the frame size";
+        return AC3MI_ERR_ARG;
+    }
+    for (int i = 0; i < 8; i++) E.chmap[i] = i < enc->channels ? chmap[i] : 0;
+    for (int i = 0; i < enc->channels; i++)
+        if (E.chmap[i] >= enc->channels) { ctx->err = "ac3mi_transcode_batch: chmap entry out of range"; return AC3MI_ERR_ARG; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t F = (size_t)frames_per_stream, nfr = (size_t)n_streams * F;
+    // workspaces: decoder planes, float PCM + s16 PCM, encoder arrays
+    { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), nfr * 6 * X.plan.nfchans + 4); if (r != AC3MI_OK) return r; }
+    const size_t pcm_bytes = nfr * 6 * n_out * 256 * sizeof(float), s16_bytes = nfr * 1536 * n_out * 2;
+    if (pcm_bytes + s16_bytes + 512 > ctx->ws_tc_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws_tc);
+        ctx->ws_tc = nullptr;
+        ctx->ws_tc_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_tc, pcm_bytes + s16_bytes + 512));
+        ctx->ws_tc_bytes = pcm_bytes + s16_bytes + 512;
+    }
+    float *ws_pcm = (float *)ctx->ws_tc;
+    int16_t *ws_s16 = (int16_t *)((uint8_t *)ctx->ws_tc + ((pcm_bytes + 255) & ~(size_t)255));
+    const size_t rows = nfr * 6 * E.cfg.nch, rows_pad = (rows + 255) & ~(size_t)255;
+    const size_t off_eexp = rows * 256 * 4 + rows * 256, off_emask = off_eexp + rows * 256;
+    const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
+    const size_t off_ebits = off_strat + rows_pad, need = off_ebits + rows_pad * 4 + 1024;
+    if (need > ctx->ws_enc_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws_enc);
+        ctx->ws_enc = nullptr;
+        ctx->ws_enc_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_enc, need));
+        ctx->ws_enc_bytes = need;
+    }
+    // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
+    // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 2 : 1;       // measured on 65536 frames: 13.0 (1), 12.7 (2), 12.75 ms (4)
+    auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
+    auto front = [&](int k) -> hipError_t {
+        const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
+        const size_t f0 = (size_t)s0 * F;
+        DecodeLaunch D;
+        D.frames = d_frames_in + f0 * in_stride;
+        D.frame_bytes = dd.frame_bytes;
+        D.frame_stride = in_stride;
+        D.n_streams = ns;
+        D.frames_per_stream = frames_per_stream;
+        D.req_flags = dd.flags;
+        D.acmod = dd.acmod;
+        D.lfeon = dd.lfeon ? 1 : 0;
+        D.dynrng_on = dd.dynrng ? 1 : 0;
+        D.level = dd.level;
+        D.coef = ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
+        D.blksw = ctx->ws_blksw + f0 * 6 * X.plan.nfchans;
+        D.status = d_status + f0;
+        D.lfsr = ctx->slots ? d_lfsr : d_lfsr + s0;
+        D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
+        D.tap_exp = nullptr;
+        D.tap_bap = nullptr;
+        return launch_decode(ctx->tab, D, ctx->stream);
+    };
+    auto middle = [&](int k, hipStream_t st) -> hipError_t {
+        const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
+        const size_t f0 = (size_t)s0 * F;
+        XformLaunch Y = X;
+        Y.coef = ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
+        Y.blksw = ctx->ws_blksw + f0 * 6 * X.plan.nfchans;
+        Y.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * n_out * 128;
+        Y.slot = ctx->slots ? ctx->slots + s0 : nullptr;
+        Y.delay_stride = 6 * 128;
+        Y.pcm = ws_pcm + f0 * 6 * n_out * 256;
+        Y.n_streams = ns;
+        Y.frames = frames_per_stream;
+        Y.bias = 384.0f;
+        hipError_t e = launch_xform(ctx->tab, Y, st);
+        if (e != hipSuccess) return e;
+        return launch_convert_s16(Y.pcm, ws_s16 + f0 * 1536 * n_out, out_flags, (size_t)ns * F * 6, st);
+    };
+    auto back = [&](int k) -> hipError_t {
+        const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
+        const size_t f0 = (size_t)s0 * F, r0 = f0 * 6 * E.cfg.nch;
+        EncodeLaunch G = E;
+        G.ws_mdct = (int32_t *)ctx->ws_enc + r0 * 256;
+        G.ws_expo = nullptr;
+        G.ws_eexp = (uint8_t *)ctx->ws_enc + off_eexp + r0 * 256;
+        G.ws_emask = (int16_t *)((uint8_t *)ctx->ws_enc + off_emask) + r0 * 50;
+        G.ws_shift = (int8_t *)ctx->ws_enc + off_shift + r0;
+        G.ws_strat = (uint8_t *)ctx->ws_enc + off_strat + r0;
+        G.ws_ebits = (int32_t *)((uint8_t *)ctx->ws_enc + off_ebits) + f0 * E.cfg.nch;
+        G.pcm = ws_s16 + f0 * 1536 * n_out;
+        G.last = ctx->slots ? d_last : d_last + (size_t)s0 * E.cfg.nch * 256;
+        G.csnr = ctx->slots ? d_csnroffst : d_csnroffst + s0;
+        G.slot = ctx->slots ? ctx->slots + s0 : nullptr;
+        G.frames = d_frames_out + f0 * out_stride;
+        G.frame_stride = out_stride;
+        G.n_streams = ns;
+        G.frames_per_stream = frames_per_stream;
+        G.tap_eexp = G.tap_bap = G.tap_strat = nullptr;
+        G.tap_snr = nullptr;
+        return launch_encode(ctx->tab, G, ctx->stream);
+    };
+    if (n_chunks == 1) {
+        HIPCHK(ctx, front(0));
+        HIPCHK(ctx, middle(0, ctx->stream));
+        HIPCHK(ctx, back(0));
+        return AC3MI_OK;
+    }
+    hipEvent_t *ev = ctx->ev_chunk;                     // front end of chunk k done
+    for (int k = 0; k < n_chunks; k++) {
+        HIPCHK(ctx, front(k));
+        HIPCHK(ctx, hipEventRecord(ev[k], ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ev[k], 0));
+        HIPCHK(ctx, middle(k, ctx->stream2));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_mid[k], ctx->stream2));
+        if (k > 0) {
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_mid[k - 1], 0));
+            HIPCHK(ctx, back(k - 1));
+        }
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_mid[n_chunks - 1], 0));
+    HIPCHK(ctx, back(n_chunks - 1));
     return AC3MI_OK;
 }
 

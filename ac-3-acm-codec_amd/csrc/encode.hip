@@ -79,7 +79,7 @@ struct MaskTabs {
 
 struct alignas(16) PackLDS {
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
-    uint32_t gtab[128];         // 3/5/11-level codes being assembled, rings of 32 / 32 / 64: code (bits 0..6) | bit offset << 8
+    uint32_t gtab[128];         // 3/5/11-level codes being assembled, rings of 32 / 32 / 64: bit offset | 16-bit code << 16
     uint32_t bitlut[64];        // see lut_index
     uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
     int8_t shiftv[36];          // exp_samples of the frame
@@ -88,6 +88,8 @@ struct alignas(16) PackLDS {
     uint16_t crc_tab[256];
 };
 
+// put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
+// the bits before the field as far as the 32-bit word it starts in, which is what the 64-bit shift below does.
 __device__ __forceinline__ void put_bits(uint32_t *fr, uint32_t pos, int n, uint32_t v)
 {
     if (n <= 0) return;
@@ -744,11 +746,12 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :15
 
 __device__ __forceinline__ int quant_sym(int c, int e, int levels)       // :1150-1166
 {
-    int v;
-    e &= 31;
-    if (c >= 0) { v = (levels * (c << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) + v; }
-    else { v = (levels * ((-c) << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) - v; }
-    return v;
+    // out of contract when e < 0 (a reuse run pulled the exponent below the block's shift): as the x86 build runs it -
+    // shift count masked to 5 bits, 32-bit wrap-around multiply, arithmetic right shift
+    const uint32_t a = (uint32_t)(c >= 0 ? c : -c) << (e & 31);
+    int v = (int32_t)((uint32_t)levels * a) >> 24;
+    v = (v + 1) >> 1;
+    return c >= 0 ? (levels >> 1) + v : (levels >> 1) - v;
 }
 __device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :1169-1190
 {
@@ -1109,16 +1112,18 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                     const int levels = bp == 1 ? 3 : bp == 2 ? 5 : bp == 4 ? 11 : bp == 3 ? 7 : 15;
                     const bool sym = grouped || bp == 3 || bp == 5;
                     const int v = sym ? quant_sym(c, e, levels) : quant_asym(c, e, w ? w : 1);
-                    if (!grouped) put_bits(L.fr, off, w, (uint32_t)v);
+                    // quantised values live in 16 bits (qmant[] is unsigned short, :1347); only out-of-contract ones are wider than their field
+                    if (!grouped) put_bits(L.fr, off, w, (uint32_t)v & 0xffffu);
 
                     // a step opens at most 22 / 22 / 32 groups and one older group per kind can be incomplete
                     uint32_t *slot = kind == 2 ? &L.gtab[64 + (grp & 63)] : &L.gtab[(kind == 1 ? 32 : 0) + (grp & 31)];
                     const int wgt = mem == per - 1 ? 1 : mem == 0 ? (kind == 2 ? 11 : levels * levels) : levels;
-                    if (opens) *slot = (off << 8) | (uint32_t)(v * wgt);
+                    // slot = bit offset | 16-bit code << 16: the code accumulates modulo 2^16 like *qmant_ptr += ...
+                    if (opens) *slot = off | ((uint32_t)(v * wgt) << 16);
                     WAVE_SYNC();
-                    if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt));
+                    if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt) << 16);
                     WAVE_SYNC();
-                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(L.fr, x >> 8, gbits, x & 0xff); }
+                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(L.fr, x & 0xffffu, gbits, x >> 16); }
 
                     b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
                     pos += wave_last(bincl);
@@ -1126,9 +1131,9 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                 // a trailing group that never got its last member is written as it stands
                 WAVE_SYNC();
                 if (lane == 0) {
-                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(L.fr, x >> 8, 5, x & 0xff); }
-                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
-                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(L.fr, x >> 8, 7, x & 0xff); }
+                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(L.fr, x & 0xffffu, 5, x >> 16); }
+                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(L.fr, x & 0xffffu, 7, x >> 16); }
+                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(L.fr, x & 0xffffu, 7, x >> 16); }
                 }
             }
             WAVE_SYNC();

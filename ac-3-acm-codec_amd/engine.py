@@ -178,6 +178,28 @@ class Engine:
             return out, status, tdict
         return out, status
 
+    def transcode_batch(self, dec, enc, frames, delay, lfsr, chmap, last, csnroffst, out=None, status=None, wait_torch=True):
+        """frames [S][F][in_stride] u8 -> re-encoded frames [S][F][out_stride] u8 (+ status [S][F]); the state arrays
+        are those of decode_batch (delay, lfsr) and encode_batch (last, csnroffst), all updated in place."""
+        import torch
+        if wait_torch:
+            torch.cuda.synchronize(self.device)
+        S, F, in_stride = frames.shape
+        fb = enc.frame_bytes()
+        stride = (fb + 3) & ~3
+        dev = frames.device
+        if out is None:
+            out = torch.zeros((S, F, stride), dtype=torch.uint8, device=dev)
+        if status is None:
+            status = torch.zeros((S, F), dtype=torch.int32, device=dev)
+        cm = (ctypes.c_uint8 * 8)(*(list(chmap) + [0] * 8)[:8])
+        dc, ec = dec.c(), enc.c()
+        self._check(self.lib.ac3mi_transcode_batch(self.ctx, ctypes.byref(dc), ctypes.byref(ec), frames.data_ptr(), in_stride, S, F,
+                                                   delay.data_ptr(), lfsr.data_ptr(), cm, last.data_ptr(), csnroffst.data_ptr(),
+                                                   out.data_ptr(), stride, status.data_ptr()))
+        self._keep.append((frames, delay, lfsr, last, csnroffst, out, status))
+        return out, status
+
     def encode_batch(self, desc, pcm, chmap, last, csnroffst, out=None, taps=False, wait_torch=True):
         """pcm [S][F][1536][nch] s16, chmap = nch ints, last [S][nch][256] s16, csnroffst [S] i32 (both
         updated in place) -> frames [S][F][stride] u8 (stride = frame bytes rounded up to 4)[, taps dict]."""

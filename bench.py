@@ -145,10 +145,13 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
         eng._check(eng.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(eng.ctx), ctypes.c_void_p(out.data_ptr()),
                                                   ctypes.c_void_p(s16.data_ptr()), 7 | 16, ctypes.c_size_t(S * 6)))
 
+    delay2 = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+    lfsr2 = torch.ones((S,), dtype=torch.int16, device=dev)
+    last2 = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+    csnr2 = torch.full((S,), 40, dtype=torch.int32, device=dev)
+
     def do_transcode():
-        do_dec()
-        do_cvt()
-        do_enc(s16.view(S, 1, 1536, 6), frames2)
+        eng.transcode_batch(dec, enc, frames, delay2, lfsr2, chmap, last2, csnr2, out=frames2, status=status, wait_torch=False)
 
     res = {}
     for name, fn, nbytes in (("encode", do_enc, 18432 + 1536 + 2 * 3072),

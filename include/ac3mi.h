@@ -233,6 +233,21 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
                        int frame_stride, int n_streams, int frames_per_stream,
                        const ac3mi_encode_taps *taps);
 
+/* ---- transcode: bitstream -> bitstream ----------------------------------------- */
+
+/* BASELINE configs[4]: decode -> s16 -> re-encode for a batch of independent streams in one call (what a host does
+ * with stream_convert_ac3 followed by stream_convert_pcm, src/AC3ACM.cpp:1498-1581, 1762).  Equivalent to
+ * ac3mi_decode_batch (level 1, bias 384; dec->level / dec->bias are ignored) + ac3mi_convert_s16_batch +
+ * ac3mi_encode_batch with the same state arrays, bit for bit; the float and s16 PCM stay in the engine's
+ * workspace, and for large batches the HBM-bound transform / conversion kernels of one chunk of streams run on a
+ * second stream under the instruction-bound front end and encoder of its neighbours.
+ * The decoder's output channel count (ac3mi_decode_planes) must equal enc->channels; chmap as in
+ * ac3mi_encode_batch, applied to the WAVE-order s16 frames. */
+int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac3mi_encode_desc *enc,
+                          const uint8_t *d_frames_in, int in_stride, int n_streams, int frames_per_stream,
+                          float *d_delay, uint16_t *d_lfsr, const uint8_t *chmap, int16_t *d_last,
+                          int32_t *d_csnroffst, uint8_t *d_frames_out, int out_stride, uint32_t *d_status);
+
 #ifdef __cplusplus
 }
 #endif

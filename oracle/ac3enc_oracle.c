@@ -485,8 +485,17 @@ static int search_allocation(orc_ac3enc_t *s, int frame_bits)
 
 /* ---------------- bit writer (replaces ac3enc.cpp:111-181) ---------------- */
 
+/* put_bits (ac3enc.cpp:148-176).  The release build does not mask `value`: bits above the field width are OR-ed
+ * onto the bits written just before it, as far as the 32-bit word the field starts in (beyond that they fall off
+ * the accumulator).  Only the out-of-contract quantiser results below can be that wide. */
 static inline void put(bitw *w, int n, unsigned v)
 {
+    uint32_t spill = n < 32 ? v >> n : 0, back = w->nbits;
+    while (spill && (back & 31)) {
+        back--;
+        if (spill & 1) w->buf[back >> 3] |= (uint8_t)(0x80 >> (back & 7));
+        spill >>= 1;
+    }
     while (n--) {
         if ((v >> n) & 1) w->buf[w->nbits >> 3] |= (uint8_t)(0x80 >> (w->nbits & 7));
         w->nbits++;
@@ -497,11 +506,13 @@ static inline void put(bitw *w, int n, unsigned v)
 
 static inline int quant_sym(int c, int e, int levels)
 {
-    int v;
-    e &= 31;                                   /* x86 shift-count masking; c == 0 whenever e > 24 */
-    if (c >= 0) { v = (levels * (c << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) + v; }
-    else { v = (levels * ((-c) << e)) >> 24; v = (v + 1) >> 1; v = (levels >> 1) - v; }
-    return v;
+    /* e = encoded exponent - block shift is negative when a reuse run pulls the exponent of a quiet, strongly
+     * normalised block below its shift: `c << e` is then undefined in C.  Restated as the x86 build executes it:
+     * shift count masked to 5 bits, 32-bit wrap-around multiply, arithmetic right shift. */
+    const uint32_t a = (uint32_t)(c >= 0 ? c : -c) << (e & 31);
+    int v = (int32_t)((uint32_t)levels * a) >> 24;
+    v = (v + 1) >> 1;
+    return c >= 0 ? (levels >> 1) + v : (levels >> 1) - v;
 }
 
 static inline int quant_asym(int c, int e, int qbits)
