@@ -43,8 +43,8 @@ struct DecLDS {
     int8_t bap[7][ROW];
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
-    uint8_t gcode[3][128];                // open 3/5/11-level codes, indexed by group number mod 128
-    float qtab[760];                      // dequantised code members (DecTables::qtab)
+    uint8_t gcode[128];                   // open 3/5/11-level codes: rings of 32 / 32 / 64 (a step opens <= 22 / 22 / 32)
+    int16_t qtab[760];                    // dequantised code members (DecTables::qtab; integers below 2^15)
     uint8_t cplbnd[20];                   // coupling sub-band -> band
     int16_t seg_base[9];                  // mantissa stream segments
     uint8_t seg_ch[8], seg_start[8];
@@ -374,7 +374,7 @@ __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t 
 
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
+__global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
 {
     __shared__ DecLDS L;
     extern __shared__ uint32_t frw[];
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
     if (lane < 50) L.hth[lane] = 0;
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
-    for (int i = lane; i < 760; i += 64) L.qtab[i] = P.tab->qtab[i];
+    for (int i = lane; i < 760; i += 64) L.qtab[i] = (int16_t)P.tab->qtab[i];
     for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
     for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
@@ -816,7 +816,8 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
 
                         uint32_t raw = 0;
                         if (nb) raw = peek(FB, off, nb);
-                        if (opens) L.gcode[kind][grp & 127] = (uint8_t)raw;
+                        const int gslot = kind == 2 ? 64 + (grp & 63) : (kind == 1 ? 32 : 0) + (grp & 31);
+                        if (opens) L.gcode[gslot] = (uint8_t)raw;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -826,10 +827,10 @@ __global__ __launch_bounds__(64) void decode_kernel(const DecodeParams P)
                         float q = 0.f;
                         {
                             const bool coded = kind >= 0 || w == 3 || w == 4;
-                            const int code = kind >= 0 ? (int)L.gcode[kind][grp & 127] : (int)raw;
+                            const int code = kind >= 0 ? (int)L.gcode[gslot] : (int)raw;
                             const int base = kind == 0 ? 0 : kind == 1 ? 96 : kind == 2 ? 480 : w == 3 ? 736 : 744;
                             const int ti = base + code * (kind >= 0 ? per : 1) + (kind >= 0 ? mem : 0);
-                            const float tv = L.qtab[coded ? ti : 0];
+                            const float tv = (float)L.qtab[coded ? ti : 0];
                             const float pv = (float)((((int32_t)(raw << ((32 - w) & 31))) >> ((32 - w) & 31)) * (1 << ((16 - w) & 31)));
                             q = coded ? tv : w > 0 ? pv : 0.f;
                         }
