@@ -87,6 +87,63 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def cpu_baseline_codec(frames, seconds_each=4.0):
+    """CPU rates beside the secondary legs, same bitstreams, whole loops in C: full frame decode with the reference's
+    own liba52 (oracle/_ref, kind "reference"; the oracle port if it is absent) and encode with the encoder oracle
+    (kind "port": the reference's ac3enc does not build here).  One stream per worker thread, a few seconds each."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import _harness as H
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    n, fb = frames.shape[0], frames.shape[2]
+    stream = np.ascontiguousarray(frames[:, 0, :])                   # n frames played as one stream per worker
+    buf = np.zeros(stream.size + 64, np.uint8)
+    buf[:stream.size] = stream.reshape(-1)
+    O = H.orc()
+    O.orc_a52_decode_frames.argtypes = [H.u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, H.fp]
+    O.orc_ac3enc_encode_frames.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, H.i16p, ctypes.c_int, H.u8p, H.u8p]
+    if H.have_ref():
+        kind = "reference"
+        R = H.ref()
+        R.refglue_decode_frames.argtypes = [H.u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, H.fp]
+
+        def dec():
+            assert R.refglue_decode_frames(H.P(buf, H.u8p), n, fb, 7 | 16, 1.0, 0.0, None) == 0
+    else:
+        kind = "port"
+
+        def dec():
+            assert O.orc_a52_decode_frames(H.P(buf, H.u8p), n, fb, 7 | 16, 1.0, 0.0, None) == 0
+    nenc = 16
+    pcm16 = np.ascontiguousarray(H.gen_pcm(nenc, 6, seed=3, kind="bursts"))
+    cm = (ctypes.c_uint8 * 8)(*H.CHMAP6)
+
+    def enc():
+        assert O.orc_ac3enc_encode_frames(48000, 384000, 6, H.P(pcm16, H.i16p), nenc, cm, None) == 0
+
+    def rate(fn, unit):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        per = time.perf_counter() - t0
+        reps = max(1, min(int(seconds_each / max(per, 1e-6)), 500))
+
+        def worker(_):
+            for _ in range(reps):
+                fn()
+            return unit * reps
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(worker, range(cores)))
+        return done / (time.perf_counter() - t0), unit / per
+
+    d_all, d_one = rate(dec, n)
+    e_all, e_one = rate(enc, nenc)
+    return {"decode": {"value": d_all, "unit": "frames/s", "cores": cores, "kind": kind, "one_thread": d_one},
+            "encode": {"value": e_all, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread": e_one}}
+
+
 def measured_traffic(frames):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/run_profile.sh),
     only if they were taken at this batch size; else None."""
@@ -175,6 +232,7 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
                      "algorithmic_bytes_per_frame": nbytes}
     ok = int((status & 0x1ff).max().item()) == 0
     res["decode"]["all_frames_ok"] = ok
+    res["_frames"] = frames[:64].cpu().numpy()          # for the CPU rates beside these legs (dropped from the line)
     if dist is None:           # host-side work on up to 16 threads: single-process runs only
         res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
@@ -331,8 +389,12 @@ def main():
             line["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+            if extra is not None and "_frames" in extra:
+                extra["cpu"] = cpu_baseline_codec(extra.pop("_frames"))
         else:
             line["cpu_baseline"] = None
+        if extra is not None:
+            extra.pop("_frames", None)
         print(json.dumps(line), flush=True)
 
     eng.close()

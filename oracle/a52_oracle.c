@@ -1690,3 +1690,4 @@ int orc_a52_decode_frames(const uint8_t *frames, int n, int frame_bytes, int fla
 }
 
 long orc_a52_bitpos(orc_a52_t *st) { return (long)st->bitpos; }
+

@@ -55,3 +55,26 @@ void refglue_imdct512_batch (sample_t * data, sample_t * delay, long n, long n_c
     for (k = 0; k < n; k++)
 	a52_imdct_512 (data + 256 * k, delay + 256 * (k % n_chains), bias);
 }
+
+/* Whole-frame decode loop in C (bench.py's CPU rate beside the decode leg): n frames of frame_bytes each, played as one
+ * stream; returns the number of a52_frame / a52_block failures.  *sink receives a checksum so the work cannot be
+ * optimised away. */
+int refglue_decode_frames (uint8_t * buf, int n, int frame_bytes, int flags, float level, float bias, float * sink)
+{
+    a52_state_t * st = a52_init (0);
+    int f, b, i, errs = 0;
+    float acc = 0;
+    if (!st) return -1;
+    for (f = 0; f < n; f++) {
+	int fl = flags;
+	level_t lv = level;
+	if (a52_frame (st, buf + (size_t) f * frame_bytes, &fl, &lv, bias)) { errs++; continue; }
+	for (b = 0; b < 6; b++) {
+	    if (a52_block (st)) { errs++; break; }
+	    for (i = 0; i < 256 * 6; i += 97) acc += a52_samples (st)[i];
+	}
+    }
+    a52_free (st);
+    if (sink) *sink = acc;
+    return errs;
+}
