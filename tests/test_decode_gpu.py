@@ -181,3 +181,28 @@ def test_exponent_error_is_reported(engine):
     assert L.orc_a52_frame(st, H.P(buf, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0) == 0
     assert L.orc_a52_block(st) == 1
     L.orc_a52_free(st)
+
+
+def test_large_batch_goes_through_the_chunk_pipeline(engine):
+    """>= 16384 frames: ac3mi_decode_batch splits the streams into four chunks and runs each chunk's transform on a
+    second HIP stream.  Replicated streams must decode to identical PCM, taps and state whatever chunk they fall in."""
+    import torch
+    pkg = H.pkg()
+    F, S = 3, 5600
+    base = [H.orc_encode(H.gen_pcm(F, 6, seed=60 + s, kind=("tones", "bursts", "music", "quiet", "noise", "strobe", "tones")[s])) for s in range(7)]
+    frames = torch.from_numpy(np.stack([base[s % 7] for s in range(S)])).cuda()
+    desc = pkg.DecodeDesc(flags=7 | 16, level=1.0, bias=0.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=base[0].shape[1])
+    delay = torch.zeros((S, 6, 128), dtype=torch.float32, device="cuda")
+    lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+    pcm, status, taps = engine.decode_batch(desc, frames, delay, lfsr, taps=True)
+    engine.sync()
+    assert int((status.cpu() & 0x1ff).max()) == 0
+    p, d, l = pcm.cpu().numpy(), delay.cpu().numpy(), lfsr.cpu().numpy()
+    c, b = taps["coef"].cpu().numpy(), taps["bap"].cpu().numpy()
+    for s in range(7, S, 13):
+        assert np.array_equal(p[s].view(np.uint32), p[s % 7].view(np.uint32)), s
+        assert np.array_equal(d[s].view(np.uint32), d[s % 7].view(np.uint32)) and l[s] == l[s % 7], s
+        assert np.array_equal(c[s].view(np.uint32), c[s % 7].view(np.uint32)) and np.array_equal(b[s], b[s % 7]), s
+    # and the first replicas agree with the oracle
+    want, errs, _ = H.orc_decode(base[1], 7 | 16, 1.0, 0.0)
+    assert errs == 0 and H.rms(p[1].astype(np.float64) - want) <= 1e-6
