@@ -87,6 +87,10 @@ struct DecodeLaunch {
     uint8_t *tap_exp;
     int8_t *tap_bap;
     const int32_t *slot;
+    // few long streams: counting pass + LFSR prefix + one wavefront per frame (decode.hip, MODE 1/2)
+    int frame_parallel;
+    uint32_t *frame_draws;  // [S][F] workspace
+    uint16_t *frame_lfsr;   // [S][F] workspace
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 void build_dec_tables(DecTables *t, uint16_t *lfsr_seq /*[65535]*/, uint16_t *lfsr_idx /*[65536]*/);
@@ -142,5 +146,8 @@ struct ac3mi_ctx {
     size_t ws_tc_bytes;
     // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
     const int32_t *slots;
+    int decode_mode;        // 0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame
+    uint32_t *ws_draws;     // [S][F] draw counts + [S][F] u16 frame-start LFSR states (decode, frame-parallel)
+    size_t ws_draws_bytes;
     std::string err;
 };

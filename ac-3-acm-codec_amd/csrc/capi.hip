@@ -390,6 +390,9 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->ws_tc = nullptr;
     ctx->ws_tc_bytes = 0;
     ctx->slots = nullptr;
+    ctx->decode_mode = 0;
+    ctx->ws_draws = nullptr;
+    ctx->ws_draws_bytes = 0;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
     ctx->ws_coef_bytes = ctx->ws_blksw_bytes = 0;
@@ -416,6 +419,7 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->ws_blksw);
     (void)hipFree(ctx->ws_enc);
     (void)hipFree(ctx->ws_tc);
+    (void)hipFree(ctx->ws_draws);
     (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -498,6 +502,35 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots)
 {
     if (!ctx) return AC3MI_ERR_ARG;
     ctx->slots = d_slots;
+    return AC3MI_OK;
+}
+
+int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return AC3MI_ERR_ARG;
+    ctx->decode_mode = mode;
+    return AC3MI_OK;
+}
+
+// frame-parallel front end for few long streams?  (auto: more than one frame per stream and too few streams to fill
+// the chip with one wavefront each: 256 CUs x 20 wavefronts)
+static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
+{
+    if (frames_per_stream < 2) return false;
+    if (ctx->decode_mode) return ctx->decode_mode == 2;
+    return n_streams < 5120;
+}
+
+static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)
+{
+    const size_t need = nfr * 4 + nfr * 2 + 256;
+    if (need <= ctx->ws_draws_bytes) return AC3MI_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->ws_draws);
+    ctx->ws_draws = nullptr;
+    ctx->ws_draws_bytes = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->ws_draws, need));
+    ctx->ws_draws_bytes = need;
     return AC3MI_OK;
 }
 
@@ -631,6 +664,8 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     if (!coef) coef = ctx->ws_coef;
     if (!blksw) blksw = ctx->ws_blksw;
 
+    const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
+    if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // A large batch goes through in four chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
     const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 4 : 1;       // measured: 4.79 -> 4.66 ms on 65536 frames
@@ -658,6 +693,9 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
         D.tap_exp = taps && taps->d_exp ? taps->d_exp + f0 * 6 * 7 * 256 : nullptr;
         D.tap_bap = taps && taps->d_bap ? taps->d_bap + f0 * 6 * 7 * 256 : nullptr;
+        D.frame_parallel = fp ? 1 : 0;
+        D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
+        D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;
         HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
 
         hipStream_t xs = ctx->stream;
@@ -836,6 +874,8 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         HIPCHK(ctx, hipMalloc(&ctx->ws_enc, need));
         ctx->ws_enc_bytes = need;
     }
+    const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
+    if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
     const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 2 : 1;       // measured on 65536 frames: 13.0 (1), 12.7 (2), 12.75 ms (4)
@@ -861,6 +901,9 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
         D.tap_exp = nullptr;
         D.tap_bap = nullptr;
+        D.frame_parallel = fp ? 1 : 0;
+        D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
+        D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;
         return launch_decode(ctx->tab, D, ctx->stream);
     };
     auto middle = [&](int k, hipStream_t st) -> hipError_t {

@@ -149,6 +149,8 @@ struct DecodeParams {
     int acmod, lfeon;       // expected coded configuration (frame 0 of the batch)
     int n_in, nfchans;
     const int32_t *slot;    // optional: stream s keeps its LFSR state in lfsr_state[slot[s]]
+    uint32_t *frame_draws;  // [S][F] dither draws of each frame (written by the counting pass)
+    const uint16_t *frame_lfsr;   // [S][F] LFSR state at the start of each frame (frame-parallel pass)
 };
 
 // ---------------------------------------------------------------------------
@@ -374,13 +376,21 @@ __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t 
 
 // ---------------------------------------------------------------------------
 
+// MODE 0: one wavefront per stream, frames in order (the dither LFSR carries from frame to frame).
+// MODE 1 + lfsr_prefix_kernel + MODE 2: for few, long streams.  Nothing else carries across the frames of a valid
+// stream (block 0 re-sends exponents, coupling and bit-allocation parameters), so a counting pass (MODE 1: one
+// wavefront per frame, everything but the mantissa values) finds each frame's number of dither draws, a prefix pass
+// turns them into the LFSR state every frame starts from, and MODE 2 decodes all frames at once.
+template <int MODE>
 __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
 {
     __shared__ DecLDS L;
     extern __shared__ uint32_t frw[];
     const FrameBits FB{frw, (uint32_t)((P.frame_bytes + 3) >> 2) + 2u};
     const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+    const int s = MODE == 0 ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)P.frames_per_stream);
+    const int f_first = MODE == 0 ? 0 : (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream);
+    const int f_end = MODE == 0 ? P.frames_per_stream : f_first + 1;
     if (s >= P.n_streams) return;
 
     // ---- constant tables into LDS ----
@@ -409,10 +419,12 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
     for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
     st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
-    st.lfsr = P.lfsr_state[sslot];
+    st.lfsr = MODE == 0 ? (uint32_t)P.lfsr_state[sslot]
+            : MODE == 2 ? (uint32_t)P.frame_lfsr[(size_t)s * P.frames_per_stream + f_first] : 1u;
     int hth_fscod = -1;
+    uint32_t frame_draws = 0;
 
-    for (int f = 0; f < P.frames_per_stream; f++) {
+    for (int f = f_first; f < f_end; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
         const uint8_t *src = P.frames + fidx * P.frame_stride;
         float *cout = P.coef + fidx * 6 * P.n_in * 256;
@@ -814,6 +826,12 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                         int cd = dbase + (int)(bincl >> 16) - nd;
                         const uint32_t gtot = wave_last(gincl), btot = wave_last(bincl);
 
+                        if (MODE == 1) {                             // counting pass: ranks, bit offsets and draw counts only
+                            b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
+                            bitbase += btot & 0xffffu;
+                            dbase += (int)(btot >> 16);
+                            continue;
+                        }
                         uint32_t raw = 0;
                         if (nb) raw = peek(FB, off, nb);
                         const int gslot = kind == 2 ? 64 + (grp & 63) : (kind == 1 ? 32 : 0) + (grp & 31);
@@ -872,8 +890,10 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                 }
                 rd.pos = bitbase;
                 const int nd_total = dbase;
+                frame_draws += (uint32_t)nd_total;
                 // advance the dither generator past this block's draws
-                if (lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
+                if (MODE != 1 && lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
+                if (MODE == 1) continue;                             // no planes in the counting pass
 
                 // zero tails: parse.c:828-834, 871-872
 #pragma unroll
@@ -887,7 +907,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
 
             // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
-            {
+            if (MODE != 1) {
                 if (err)
                     for (int c = 0; c < P.n_in; c++)
                         *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -897,9 +917,27 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) P.status[fidx] = status;
+        if (MODE != 1 && lane == 0) P.status[fidx] = status;
+        if (MODE == 1 && lane == 0) P.frame_draws[fidx] = frame_draws;
     }
-    if (lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
+    if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
+    if (MODE == 2 && lane == 0 && f_end == P.frames_per_stream) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
+}
+
+// LFSR state at the start of every frame: one thread per stream walks its frames' draw counts (the generator is
+// GF(2)-linear with period 65535: k draws = k positions along the cycle; state 0 is a fixed point).
+__global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, const uint16_t *lfsr_state, const int32_t *slot,
+                                   const uint16_t *seq, const uint16_t *idx, int n_streams, int frames)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    uint32_t state = lfsr_state[slot ? slot[s] : s];
+    uint32_t pos = idx[state];
+    for (int f = 0; f < frames; f++) {
+        frame_lfsr[(size_t)s * frames + f] = (uint16_t)state;
+        const uint32_t k = draws[(size_t)s * frames + f];
+        if (state != 0 && k) { pos = (pos + k) % 65535u; state = seq[pos]; }
+    }
 }
 
 }  // namespace ac3mi
@@ -933,8 +971,21 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     P.nfchans = nfch[L.acmod & 7];
     P.n_in = P.nfchans + (L.lfeon ? 1 : 0);
     if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
+    P.frame_draws = L.frame_draws;
+    P.frame_lfsr = L.frame_lfsr;
     const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 4) * 4;
-    hipLaunchKernelGGL(decode_kernel, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
+    if (!L.frame_parallel) {
+        hipLaunchKernelGGL(decode_kernel<0>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
+        return hipGetLastError();
+    }
+    const unsigned units = (unsigned)L.n_streams * (unsigned)L.frames_per_stream;
+    DecodeParams C = P;                                 // counting pass: no outputs but the draw counts
+    C.tap_exp = nullptr;
+    C.tap_bap = nullptr;
+    hipLaunchKernelGGL(decode_kernel<1>, dim3(units), dim3(64), fr_bytes, stream, C);
+    hipLaunchKernelGGL(lfsr_prefix_kernel, dim3((L.n_streams + 63) / 64), dim3(64), 0, stream, (const uint32_t *)L.frame_draws,
+                       L.frame_lfsr, (const uint16_t *)L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);
+    hipLaunchKernelGGL(decode_kernel<2>, dim3(units), dim3(64), fr_bytes, stream, P);
     return hipGetLastError();
 }
 

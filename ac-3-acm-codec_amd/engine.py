@@ -178,6 +178,10 @@ class Engine:
             return out, status, tdict
         return out, status
 
+    def set_decode_mode(self, mode):
+        """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame (ac3mi_set_decode_mode)."""
+        self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
+
     def transcode_batch(self, dec, enc, frames, delay, lfsr, chmap, last, csnroffst, out=None, status=None, wait_torch=True):
         """frames [S][F][in_stride] u8 -> re-encoded frames [S][F][out_stride] u8 (+ status [S][F]); the state arrays
         are those of decode_batch (delay, lfsr) and encode_batch (last, csnroffst), all updated in place."""

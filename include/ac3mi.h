@@ -100,6 +100,14 @@ typedef struct {
  * d_lfsr 1, d_last 6*256 samples, d_csnroffst 1.  Pass NULL to return to "stream s uses entry s". */
 int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
 
+/* How ac3mi_decode_batch / ac3mi_transcode_batch spread the front end over the GPU (new; results are identical):
+ *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame);
+ *   2  for few, long streams: a counting pass finds every frame's number of dither draws, a prefix pass the generator
+ *      state each frame starts from, then one wavefront per frame decodes them all at once.  Relies on what the AC-3
+ *      syntax guarantees: block 0 of a frame re-sends exponents, coupling and bit-allocation parameters;
+ *   0  (default) choose by batch shape. */
+int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
+
 /* Number of input planes (lfeon + fbw channels of acmod) and of output planes
  * for a descriptor; negative on an invalid combination. */
 int ac3mi_xform_planes(const ac3mi_xform_desc *desc, int *n_in, int *n_out);

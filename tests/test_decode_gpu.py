@@ -206,3 +206,46 @@ def test_large_batch_goes_through_the_chunk_pipeline(engine):
     # and the first replicas agree with the oracle
     want, errs, _ = H.orc_decode(base[1], 7 | 16, 1.0, 0.0)
     assert errs == 0 and H.rms(p[1].astype(np.float64) - want) <= 1e-6
+
+
+@pytest.mark.parametrize("source", ["encoder", "packer"])
+def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
+    """ac3mi_set_decode_mode: 1 = one wavefront per stream (frames in order), 2 = counting pass + LFSR prefix + one
+    wavefront per frame.  Same PCM, status, taps and final LFSR state, bit for bit - on encoder output (dither-heavy
+    "quiet" streams included) and on packer streams with coupling, rematrixing, delta bit allocation."""
+    import torch
+    from tests import packer
+    pkg = H.pkg()
+    if source == "encoder":
+        F, acmod, lfe = 6, 7, 1
+        streams = [H.orc_encode(H.gen_pcm(F, 6, seed=900 + s, kind=("quiet", "tones", "bursts", "music", "noise")[s % 5])) for s in range(10)]
+    else:
+        F, acmod, lfe = 5, 2, 0
+        streams = [packer.make_stream(4000 + s, F, acmod, lfe, fscod=0, bsid=8, frmsizecod=30) for s in range(10)]
+    frames = np.stack(streams)
+    fb = frames.shape[2]
+    stride = (fb + 3) & ~3
+    padded = np.zeros((frames.shape[0], F, stride), np.uint8)
+    padded[:, :, :fb] = frames
+    S = padded.shape[0]
+    flags = acmod | (16 if lfe else 0)
+    desc = pkg.DecodeDesc(flags=flags, level=1.0, bias=0.0, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
+    n_out, _ = engine.decode_planes(desc)
+    res = {}
+    try:
+        for mode in (1, 2):
+            engine.set_decode_mode(mode)
+            delay = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
+            lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+            lfsr[3] = 0x1234                         # a stream in mid-sequence
+            lfsr[4] = 0                              # the generator's fixed point: no dither at all
+            pcm, status, taps = engine.decode_batch(desc, torch.from_numpy(padded).cuda(), delay, lfsr, taps=True)
+            engine.sync()
+            # (the exponent tap also dumps rows and bins the frame does not define: leftovers of earlier frames in one mode,
+            # zeros in the other; every defined exponent shapes the coefficient planes compared here)
+            res[mode] = [x.cpu().numpy() for x in (pcm, status, delay, lfsr, taps["coef"], taps["blksw"])]
+    finally:
+        engine.set_decode_mode(0)
+    assert (res[1][1] & 0x1ff).max() == 0
+    for a, b in zip(res[1], res[2]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
