@@ -32,6 +32,9 @@ struct XformParams {
     int8_t mix[6][6];
     const int32_t *slot;        // optional: stream s keeps its overlap state in slot[s]
     int delay_stride;           // floats per state slot (n_out * 128 without slots)
+    // few long streams: a chain is cut into n_seg segments of seg_blocks blocks, one 8-lane group each.  A block's
+    // overlap tail depends on the block before it only, so a segment first re-derives the tail of the block ahead of it.
+    int n_seg, seg_blocks;
 };
 
 // long-block input pattern: lane l8 owns m = 8*n1 + l8
@@ -71,12 +74,13 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     const int tid = threadIdx.x;
     const int l8 = tid & 7;
     const int group = tid >> 3;                     // 0..31 inside the workgroup
-    const int chain = blockIdx.x * 32 + group;
+    const int vchain = blockIdx.x * 32 + group;     // (chain, segment)
+    const int chain = vchain / P.n_seg, seg = vchain - chain * P.n_seg;
     // constants shared by the whole workgroup live in LDS (registers are the scarce resource here)
     if (tid < 128) lds_twl[tid] = P.tw_long[tid];
     lds_win[tid] = P.window[tid];
     __syncthreads();
-    if (chain >= P.n_chains) return;                // whole 8-lane groups leave together
+    if (chain >= P.n_chains) return;                // whole 8-lane groups leave together (chain = vchain / n_seg)
     float2 *ex = lds_ex + group * EX_GROUP;
     const float2 *twl = lds_twl + l8 * 16;
 
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
-        dl[j] = *reinterpret_cast<const float2 *>(dptr + 2 * i);
+        dl[j] = seg == 0 ? *reinterpret_cast<const float2 *>(dptr + 2 * i) : make_float2(0.f, 0.f);
     }
 
     const size_t in_stride_blk = (size_t)P.n_in * 256;
@@ -98,7 +102,9 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     const uint8_t *swbase = P.blksw ? P.blksw + (size_t)s * P.frames * 6 * P.nfchans : nullptr;
 
     const int nblk = P.frames * 6;
-    for (int b = 0; b < nblk; b++) {
+    const int b_lo = seg * P.seg_blocks, b_hi = b_lo + P.seg_blocks < nblk ? b_lo + P.seg_blocks : nblk;
+    for (int b = seg ? b_lo - 1 : b_lo; b < b_hi; b++) {
+        const bool emit = b >= b_lo;                // the block ahead of a segment only supplies its tail
         const float *cblk = cbase + (size_t)b * in_stride_blk;
         FirstTail ft;
 #pragma unroll
@@ -169,17 +175,21 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             lo.y = ft.f1[j] * wlo.y + (dl[j].y * whi.x + P.bias);          // out[2i+1]
             hi.x = dl[j].y * wlo.y + P.bias - ft.f1[j] * whi.x;            // out[254-2i]
             hi.y = dl[j].x * wlo.x + P.bias - ft.f0[j] * whi.y;            // out[255-2i]
-            *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
-            *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
+            if (emit) {
+                *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
+                *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
+            }
             dl[j].x = ft.t0[j];
             dl[j].y = ft.t1[j];
         }
     }
 
+    if (b_hi == nblk) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
-        *reinterpret_cast<float2 *>(dptr + 2 * i) = dl[j];
+        for (int j = 0; j < 8; j++) {
+            const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+            *reinterpret_cast<float2 *>(dptr + 2 * i) = dl[j];
+        }
     }
 }
 
@@ -209,7 +219,17 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
             if (o < L.plan.n_out && c < L.plan.n_in && L.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
         }
     if (P.n_chains <= 0 || P.frames <= 0) return hipSuccess;
-    const int grid = (P.n_chains + 31) / 32;
+    // enough 8-lane groups to fill the chip (256 CUs x 4 workgroups x 32 groups): cut long chains into whole-frame segments
+    P.n_seg = 1;
+    if (P.frames > 1 && P.n_chains < 32768) {
+        int want = (32768 + P.n_chains - 1) / P.n_chains;
+        if (want > P.frames) want = P.frames;
+        const int frames_per_seg = (P.frames + want - 1) / want;
+        P.n_seg = (P.frames + frames_per_seg - 1) / frames_per_seg;
+        P.seg_blocks = frames_per_seg * 6;
+    }
+    if (P.n_seg == 1) P.seg_blocks = P.frames * 6;
+    const int grid = (int)(((long long)P.n_chains * P.n_seg + 31) / 32);
     // 4 workgroups per CU (LDS: 40 KB each); measured on MI355X: 3 vs 4 waves/SIMD, packed vs scalar f32 and
     // 8- vs 16-byte accesses all land within 1 % - the kernel runs at the rate of a plain copy with the same
     // addressing (profiles/r01_xform_probes.md)
