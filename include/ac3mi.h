@@ -179,9 +179,11 @@ int ac3mi_decode_planes(const ac3mi_decode_desc *desc, int *n_out, int *out_flag
  * d_status  [n_streams][frames_per_stream]: bit b (0..5) = a52_block b returned 1 (that block and
  *           the rest of the frame are silence), bit 8 = a52_syncinfo/a52_frame refused the frame,
  *           bits 16..23 = output flags a52_frame granted
- * Exponent / bit-allocation / coupling state is carried from frame to frame inside one call
- * exactly as a52_state_s does; across calls only d_delay and d_lfsr persist (every valid AC-3
- * frame re-sends the rest in block 0).
+ * Across frames only d_delay and d_lfsr matter for a valid stream (block 0 of every AC-3 frame re-sends
+ * exponents, coupling and bit-allocation parameters), and only they persist across calls.  Inside one call
+ * the serial front end (ac3mi_set_decode_mode 1) additionally carries exponent / bit-allocation / coupling
+ * state from frame to frame exactly as a52_state_s does, which only shows on streams that break that rule;
+ * the frame-parallel front end (mode 2, chosen automatically for few long streams) starts every frame clean.
  */
 int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
                        int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
