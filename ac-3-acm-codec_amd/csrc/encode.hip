@@ -49,6 +49,7 @@ struct PackParams {
     const int8_t *shift;
     int32_t *csnr_state;        // [S] in/out
     const int32_t *slot;        // optional: stream s uses csnr_state[slot[s]]
+    int32_t *snr;               // [S][F][2] csnroffst, fsnroffst between the two parts of the split kernel
     uint8_t *frames;            // [S][F][stride]
     const EncTables *tab;
     // taps (optional)
@@ -786,11 +787,18 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
     return __shfl(crc, 63, 64);
 }
 
+// PART 0: one wavefront per stream does everything, frames in order.
+// PART 1 + PART 2: for few, long streams.  Only the search carries something from frame to frame (it starts from the
+// previous frame's csnroffst), so PART 1 (one wavefront per stream) runs the searches and leaves csnroffst / fsnroffst
+// of every frame in P.snr, and PART 2 (one wavefront per frame) packs all frames at once.
+template <int PART>
 __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
     const int lane = threadIdx.x;
-    const int s = blockIdx.x;
+    const int s = PART == 2 ? (int)(blockIdx.x / (unsigned)P.frames_per_stream) : (int)blockIdx.x;
+    const int f_first = PART == 2 ? (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream) : 0;
+    const int f_end = PART == 2 ? f_first + 1 : P.frames_per_stream;
     if (s >= P.n_streams) return;
 
     for (int i = lane; i < 256; i += 64) {
@@ -809,9 +817,9 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
     const int fs = P.frame_words;
 
     const int sslot = P.slot ? P.slot[s] : s;
-    int csnr_prev = P.csnr_state[sslot];
+    int csnr_prev = PART == 2 ? 0 : P.csnr_state[sslot];
 
-    for (int f = 0; f < P.frames_per_stream; f++) {
+    for (int f = f_first; f < f_end; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
@@ -836,7 +844,8 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
             if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
         }
         int frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
-        for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
+        if (PART != 1)
+            for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
         WAVE_SYNC();
 
         // ---- fixed side information (:880-916) ----
@@ -882,6 +891,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
             for (int b = 0; b < 6; b++)
                 if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
         SnrSearch ss{csnr_prev, 0, 0, false};
+        if (PART == 2) { ss.csnr = P.snr[fidx * 2]; ss.fsnr = P.snr[fidx * 2 + 1]; ss.phase = 5; }      // PART 1 found them
         // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
         // known_f / fits_f for (csnroffst f_cc, ff > 0).  The reference asks for some offsets twice.
         uint64_t known_c = 0, fits_c = 0;
@@ -990,6 +1000,10 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         if (P.tap_strat && lane < 36) {
             const int b = lane / 6, ch = lane - 6 * b;
             if (ch < nch) P.tap_strat[(fidx * 6 + b) * nch + ch] = L.strat[b][ch];
+        }
+        if (PART == 1) {                    // the packer of this frame is another wavefront
+            if (lane == 0) { P.snr[fidx * 2] = csnr; P.snr[fidx * 2 + 1] = fsnr; }
+            continue;
         }
 
         // ---- header (:1113-1147) ----
@@ -1163,7 +1177,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         }
         WAVE_SYNC();
     }
-    if (lane == 0) P.csnr_state[sslot] = csnr_prev;
+    if (PART != 2 && lane == 0) P.csnr_state[sslot] = csnr_prev;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1259,7 +1273,14 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
         P.pw1[k] = h_gf_pow(2, 8u * P.c1 * (1u << k));
         P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
     }
-    hipLaunchKernelGGL(enc_pack_kernel, dim3(E.n_streams), dim3(64), 0, stream, P);
+    P.snr = E.ws_snr;
+    if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {
+        // few long streams: searches per stream, then all frames packed at once
+        hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
+        hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
+    } else {
+        hipLaunchKernelGGL(enc_pack_kernel<0>, dim3(E.n_streams), dim3(64), 0, stream, P);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame
