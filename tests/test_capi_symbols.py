@@ -86,3 +86,14 @@ def test_decode_planes_table():
                     exp_flags = out | (16 if (lfeon and want_lfe) else 0)
                     assert fl.value == exp_flags, (acmod, req, lfeon, want_lfe, fl.value, exp_flags)
                     assert n_out.value == H.NFCHANS[out] + (1 if exp_flags & 16 else 0)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h is the boundary a C host compiles against: C99, no C++ or HIP constructs."""
+    src = tmp_path / "all_headers.c"
+    src.write_text('#include "ac3mi.h"\n#include "ac3mi_stream.h"\n#include "ac3mi_dropin.h"\n'
+                   'int main(void) { ac3mi_decode_desc d = {0}; ac3mi_wavefmt w = {0}; ac3mi_stream_header h = {0};\n'
+                   '  return (int)(sizeof d + sizeof w + sizeof h) == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(H.ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
