@@ -110,7 +110,8 @@ struct EncodeLaunch {
     int16_t *ws_emask;          // [S][F][6][nch][50]  masking curves minus the floor
     uint8_t *ws_strat;          // [S][F][6][nch]
     int32_t *ws_ebits;          // [S][F][nch]
-    int32_t *ws_snr;            // [S][F][2] search results between the two parts of the split pack kernel (may be null)
+    int32_t *ws_snr;            // [S][F][2] search results between the parts of the split pack kernel (may be null)
+    uint32_t *ws_memo;          // [S][F][8] tabulated fit verdicts (may be null: the replay then costs everything itself)
     uint8_t *tap_eexp, *tap_bap, *tap_strat;
     int32_t *tap_snr;
     const int32_t *slot;

@@ -774,7 +774,8 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
     const size_t off_ebits = off_strat + rows_pad;
     const size_t off_snr = off_ebits + rows_pad * 4;
-    const size_t need = off_snr + rows_pad * 2 + 1024;       // [S][F][2] int32 <= rows / 3 entries
+    const size_t off_memo = off_snr + rows_pad * 2;              // [S][F][2] int32 <= rows / 3 entries
+    const size_t need = off_memo + rows_pad * 6 + 1024;          // [S][F][8] uint32
     if (need > ctx->ws_enc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_enc);
@@ -791,6 +792,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     E.ws_strat = (uint8_t *)ctx->ws_enc + off_strat;
     E.ws_ebits = (int32_t *)((uint8_t *)ctx->ws_enc + off_ebits);
     E.ws_snr = (int32_t *)((uint8_t *)ctx->ws_enc + off_snr);
+    E.ws_memo = (uint32_t *)((uint8_t *)ctx->ws_enc + off_memo);
     if (taps && taps->d_mdct) E.ws_mdct = taps->d_mdct;
     if (taps && taps->d_exponent) E.ws_expo = taps->d_exponent;
     if (taps && taps->d_exp_samples) E.ws_shift = taps->d_exp_samples;
@@ -867,7 +869,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     const size_t rows = nfr * 6 * E.cfg.nch, rows_pad = (rows + 255) & ~(size_t)255;
     const size_t off_eexp = rows * 256 * 4 + rows * 256, off_emask = off_eexp + rows * 256;
     const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
-    const size_t off_ebits = off_strat + rows_pad, off_snr = off_ebits + rows_pad * 4, need = off_snr + rows_pad * 2 + 1024;
+    const size_t off_ebits = off_strat + rows_pad, off_snr = off_ebits + rows_pad * 4, off_memo = off_snr + rows_pad * 2, need = off_memo + rows_pad * 6 + 1024;
     if (need > ctx->ws_enc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_enc);
@@ -937,6 +939,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         G.ws_strat = (uint8_t *)ctx->ws_enc + off_strat + r0;
         G.ws_ebits = (int32_t *)((uint8_t *)ctx->ws_enc + off_ebits) + f0 * E.cfg.nch;
         G.ws_snr = (int32_t *)((uint8_t *)ctx->ws_enc + off_snr) + f0 * 2;
+        G.ws_memo = (uint32_t *)((uint8_t *)ctx->ws_enc + off_memo) + f0 * 8;
         G.pcm = ws_s16 + f0 * 1536 * n_out;
         G.last = ctx->slots ? d_last : d_last + (size_t)s0 * E.cfg.nch * 256;
         G.csnr = ctx->slots ? d_csnroffst : d_csnroffst + s0;

@@ -49,7 +49,8 @@ struct PackParams {
     const int8_t *shift;
     int32_t *csnr_state;        // [S] in/out
     const int32_t *slot;        // optional: stream s uses csnr_state[slot[s]]
-    int32_t *snr;               // [S][F][2] csnroffst, fsnroffst between the two parts of the split kernel
+    int32_t *snr;               // [S][F][2] csnroffst, fsnroffst between the parts of the split kernel
+    uint32_t *memo;             // [S][F][8] tabulated fit verdicts (PART 3 -> PART 1): known_c, fits_c (64 bit each), known_f, fits_f, f_cc
     uint8_t *frames;            // [S][F][stride]
     const EncTables *tab;
     // taps (optional)
@@ -788,17 +789,20 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
 }
 
 // PART 0: one wavefront per stream does everything, frames in order.
-// PART 1 + PART 2: for few, long streams.  Only the search carries something from frame to frame (it starts from the
-// previous frame's csnroffst), so PART 1 (one wavefront per stream) runs the searches and leaves csnroffst / fsnroffst
-// of every frame in P.snr, and PART 2 (one wavefront per frame) packs all frames at once.
+// PART 3 + PART 1 + PART 2: for few, long streams.  Only the search carries something from frame to frame (it starts
+// from the previous frame's csnroffst).  PART 3 (one wavefront per frame) tabulates the fit verdicts around every
+// frame's own optimum; PART 1 (one wavefront per stream) replays the reference's search sequence frame after frame
+// from those tables - costing an offset itself only when the table has no answer - and leaves csnroffst / fsnroffst
+// of every frame in P.snr; PART 2 (one wavefront per frame) packs all frames at once.
 template <int PART>
 __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
     const int lane = threadIdx.x;
-    const int s = PART == 2 ? (int)(blockIdx.x / (unsigned)P.frames_per_stream) : (int)blockIdx.x;
-    const int f_first = PART == 2 ? (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream) : 0;
-    const int f_end = PART == 2 ? f_first + 1 : P.frames_per_stream;
+    constexpr bool PER_FRAME = PART == 2 || PART == 3;
+    const int s = PER_FRAME ? (int)(blockIdx.x / (unsigned)P.frames_per_stream) : (int)blockIdx.x;
+    const int f_first = PER_FRAME ? (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream) : 0;
+    const int f_end = PER_FRAME ? f_first + 1 : P.frames_per_stream;
     if (s >= P.n_streams) return;
 
     for (int i = lane; i < 256; i += 64) {
@@ -824,72 +828,67 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
-        // ---- masking curves, strategies and exponent bit counts from exp_stage (the encoded exponents
-        //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
         const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
-        {
-            const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
-            uint32_t mv[15];
+        int frame_bits = 0;
+        bool loaded = false;
+        auto load_frame = [&]() {
+            loaded = true;
+        // ---- masking curves, strategies and exponent bit counts from exp_stage (the encoded exponents
+            //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
+            {
+                const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
+                uint32_t mv[15];
 #pragma unroll
-            for (int j = 0; j < 15; j++) {
-                const int i = lane + 64 * j;
-                mv[j] = i < 6 * nch * 25 ? gm[i] : 0;
-            }
+                for (int j = 0; j < 15; j++) {
+                    const int i = lane + 64 * j;
+                    mv[j] = i < 6 * nch * 25 ? gm[i] : 0;
+                }
 #pragma unroll
-            for (int j = 0; j < 15; j++) {
-                const int i = lane + 64 * j;
-                const int row = i / 25, w = i - 25 * row, b = row / nch, ch = row - b * nch;
-                if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = mv[j];
+                for (int j = 0; j < 15; j++) {
+                    const int i = lane + 64 * j;
+                    const int row = i / 25, w = i - 25 * row, b = row / nch, ch = row - b * nch;
+                    if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = mv[j];
+                }
+                if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             }
-            if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
-        }
-        int frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
-        if (PART != 1)
-            for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
-        WAVE_SYNC();
+            frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
+            if (PART != 1)
+                for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
+            WAVE_SYNC();
 
-        // ---- fixed side information (:880-916) ----
-        {
-            const int extra[8] = {0, 0, 2, 2, 2, 4, 2, 4};
-            frame_bits += 65 + extra[P.acmod & 7];
-            for (int b = 0; b < 6; b++) {
-                frame_bits += nfbw * 2 + 2;
-                if (P.acmod == 2) frame_bits++;
-                frame_bits += 2 * nfbw;
-                if (P.lfe) frame_bits++;
-                for (int ch = 0; ch < nfbw; ch++)
-                    if (L.strat[b][ch] != 0) frame_bits += 6 + 2;
-                frame_bits += 1 + 1 + 2;
+            // ---- fixed side information (:880-916) ----
+            {
+                const int extra[8] = {0, 0, 2, 2, 2, 4, 2, 4};
+                frame_bits += 65 + extra[P.acmod & 7];
+                for (int b = 0; b < 6; b++) {
+                    frame_bits += nfbw * 2 + 2;
+                    if (P.acmod == 2) frame_bits++;
+                    frame_bits += 2 * nfbw;
+                    if (P.lfe) frame_bits++;
+                    for (int ch = 0; ch < nfbw; ch++)
+                        if (L.strat[b][ch] != 0) frame_bits += 6 + 2;
+                    frame_bits += 1 + 1 + 2;
+                }
+                frame_bits++;
+                frame_bits += 2 * 4 + 3 + 6 + nch * (4 + 3);
+                frame_bits += 2;
+                frame_bits += 16;
             }
-            frame_bits++;
-            frame_bits += 2 * 4 + 3 + 6 + nch * (4 + 3);
-            frame_bits += 2;
-            frame_bits += 16;
-        }
 
-        if (lane < 36) {
-            const int b = lane / 6, ch = lane - 6 * b;
-            L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
-        }
-        WAVE_SYNC();
+            if (lane < 36) {
+                const int b = lane / 6, ch = lane - 6 * b;
+                L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
+            }
+            WAVE_SYNC();
+        };
+        // PART 1 replays the search from tabulated verdicts and needs the frame's data only for a verdict that is missing
+        if (PART != 1 || P.tap_strat) load_frame();
 
         // ---- SNR offset search, exactly the reference's sequence (:921-967).  Up to three candidates are
         //      evaluated per sweep over the coefficients, chosen by running the reference's loop ahead on
         //      the assumption that each one fits; the verdicts are then consumed in the reference's order
         //      and everything after the first surprise is discarded. ----
-        const int budget = 16 * fs - frame_bits;
-        // bit 8*ch + b: block b sends new exponents for channel ch
-        uint64_t run_starts = 0;
-        for (int ch = 0; ch < nch; ch++) {
-            const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
-            run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
-        }
         const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&L.band_of_bin[4 * lane]);    // bands of bins 4*lane..+3
-        // rows (blk * 6 + ch) that start a run of exponent reuse, as a bit set
-        uint64_t row_set = 0;
-        for (int ch = 0; ch < nch; ch++)
-            for (int b = 0; b < 6; b++)
-                if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
         SnrSearch ss{csnr_prev, 0, 0, false};
         if (PART == 2) { ss.csnr = P.snr[fidx * 2]; ss.fsnr = P.snr[fidx * 2 + 1]; ss.phase = 5; }      // PART 1 found them
         // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
@@ -897,47 +896,37 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         uint64_t known_c = 0, fits_c = 0;
         uint32_t known_f = 0, fits_f = 0;
         int f_cc = -1;
+        if (PART == 1 && P.memo) {                                  // tabulated by PART 3
+            const uint32_t *m = P.memo + fidx * 8;
+            auto word = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)m[i]); };    // (the builtin returns int)
+            known_c = (uint64_t)word(0) | ((uint64_t)word(1) << 32);
+            fits_c = (uint64_t)word(2) | ((uint64_t)word(3) << 32);
+            known_f = word(4);
+            fits_f = word(5);
+            f_cc = (int)word(6);
+        }
         bool went_down = false, went_up = false;
         auto lookup = [&](int cc, int ff, bool &fits) {
             if (ff == 0) { fits = (fits_c >> cc) & 1; return (bool)((known_c >> cc) & 1); }
             fits = (fits_f >> ff) & 1;
             return cc == f_cc && ((known_f >> ff) & 1);
         };
-        for (;;) {
-            // advance the reference's loop as far as the known verdicts reach
-            int cc, ff;
-            bool more;
-            while ((more = ss.next(cc, ff))) {
-                bool fits;
-                if (!lookup(cc, ff, fits)) break;
-                if (ss.phase == 0 && !fits) went_down = true;
-                if (ss.phase == 1 && fits) went_up = true;
-                ss.consume(fits);
+        // Mantissa bits of the whole frame at up to three offsets, and the verdicts into the memo.  Bit allocation
+        // is a function of the (encoded) exponents alone, so a block that reuses a channel's exponents has that
+        // channel's counts of the block that sent them: every run of blocks is counted once, 64 bins per step, and
+        // added to the per-lane accumulators of all blocks of the run.
+        auto cost_and_record = [&](const int *so, const int *cand_c, const int *cand_f, int n_cand) {
+            if (!loaded) load_frame();
+            const int budget = 16 * fs - frame_bits;
+            // bit 8*ch + b: block b sends new exponents for channel ch; rows (blk * 6 + ch) that start a run, as a bit set
+            uint64_t run_starts = 0, row_set = 0;
+            for (int ch = 0; ch < nch; ch++) {
+                const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
+                run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
             }
-            if (!more) break;
-            // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
-            // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
-            int so[3], cand_c[3], cand_f[3], n_cand = 0;
-            {
-                SnrSearch ahead = ss;
-                while (n_cand < 3 && ahead.next(cc, ff)) {
-                    bool fits;
-                    if (!lookup(cc, ff, fits)) {
-                        bool dup = false;
-                        for (int i = 0; i < n_cand; i++) dup = dup || (cand_c[i] == cc && cand_f[i] == ff);
-                        if (dup) break;
-                        const int v = (((cc - 15) << 4) + ff) << 2;
-                        if (n_cand == 0) so[0] = so[1] = so[2] = v;
-                        cand_c[n_cand] = cc; cand_f[n_cand] = ff;
-                        so[n_cand++] = v;
-                        fits = ahead.phase == 0 ? !went_down : ahead.phase == 1 ? went_up : true;
-                    }
-                    ahead.consume(fits);
-                }
-            }
-            // Bit allocation is a function of the (encoded) exponents alone, so a block that reuses a channel's
-            // exponents has that channel's counts of the block that sent them: every run of blocks is counted
-            // once, 64 bins per step, and added to the per-lane accumulators of all blocks of the run.
+            for (int ch = 0; ch < nch; ch++)
+                for (int b = 0; b < 6; b++)
+                    if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
             uint32_t acc[6][3];
 #pragma unroll
             for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
@@ -991,6 +980,65 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                     fits_f |= (uint32_t)ok << cand_f[i];
                 }
             }
+        };
+        for (;;) {
+            // advance the reference's loop as far as the known verdicts reach
+            int cc, ff;
+            bool more;
+            while ((more = ss.next(cc, ff))) {
+                bool fits;
+                if (!lookup(cc, ff, fits)) break;
+                if (ss.phase == 0 && !fits) went_down = true;
+                if (ss.phase == 1 && fits) went_up = true;
+                ss.consume(fits);
+            }
+            if (!more) break;
+            // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
+            // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
+            int so[3], cand_c[3], cand_f[3], n_cand = 0;
+            {
+                SnrSearch ahead = ss;
+                while (n_cand < 3 && ahead.next(cc, ff)) {
+                    bool fits;
+                    if (!lookup(cc, ff, fits)) {
+                        bool dup = false;
+                        for (int i = 0; i < n_cand; i++) dup = dup || (cand_c[i] == cc && cand_f[i] == ff);
+                        if (dup) break;
+                        const int v = (((cc - 15) << 4) + ff) << 2;
+                        if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                        cand_c[n_cand] = cc; cand_f[n_cand] = ff;
+                        so[n_cand++] = v;
+                        fits = ahead.phase == 0 ? !went_down : ahead.phase == 1 ? went_up : true;
+                    }
+                    ahead.consume(fits);
+                }
+            }
+            cost_and_record(so, cand_c, cand_f, n_cand);
+        }
+        if (PART == 3) {
+            // Tabulation for the replay (PART 1), whose start value is the previous frame's result, not this pass's:
+            // every csnroffst within reach of this frame's own optimum, so that the replay finds its questions
+            // answered unless the fit is not monotone around here or the level jumps between frames.
+            const int C = ss.failed ? 0 : ss.csnr;
+            for (;;) {
+                int so[3], cand_c[3], cand_f[3], n_cand = 0;
+                for (int c = C - 7 < 0 ? 0 : C - 7; c <= (C + 8 > 63 ? 63 : C + 8) && n_cand < 3; c++) {
+                    if ((known_c >> c) & 1) continue;
+                    const int v = ((c - 15) << 4) << 2;
+                    if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                    cand_c[n_cand] = c; cand_f[n_cand] = 0;
+                    so[n_cand++] = v;
+                }
+                if (n_cand == 0) break;
+                cost_and_record(so, cand_c, cand_f, n_cand);
+            }
+            if (lane == 0) {
+                uint32_t *m = P.memo + fidx * 8;
+                m[0] = (uint32_t)known_c; m[1] = (uint32_t)(known_c >> 32);
+                m[2] = (uint32_t)fits_c; m[3] = (uint32_t)(fits_c >> 32);
+                m[4] = known_f; m[5] = fits_f; m[6] = (uint32_t)f_cc; m[7] = 0;
+            }
+            continue;
         }
         int csnr = ss.csnr, fsnr = ss.fsnr;
         if (!ss.failed) csnr_prev = csnr;
@@ -1177,7 +1225,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         }
         WAVE_SYNC();
     }
-    if (PART != 2 && lane == 0) P.csnr_state[sslot] = csnr_prev;
+    if ((PART == 0 || PART == 1) && lane == 0) P.csnr_state[sslot] = csnr_prev;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1274,8 +1322,11 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
         P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
     }
     P.snr = E.ws_snr;
+    P.memo = nullptr;
     if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {
         // few long streams: searches per stream, then all frames packed at once
+        P.memo = E.ws_memo;
+        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
     } else {
