@@ -1325,7 +1325,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.memo = nullptr;
     if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {
         // few long streams: searches per stream, then all frames packed at once
-        P.memo = E.ws_memo;
+        P.memo = E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
         if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
