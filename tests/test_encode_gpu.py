@@ -152,3 +152,29 @@ def test_encode_second_generation_content(engine, kind):
     got, _ = _gpu(engine, pcm2, 6, 384000, taps=False)
     bad = [(s, f, int((got[s, f] != want[s, f]).sum())) for s in range(4) for f in range(3) if not np.array_equal(got[s, f], want[s, f])]
     assert not bad, bad
+
+
+def test_batch_shape_paths_agree(engine):
+    """One call with six frames per stream goes through the tabulate / replay / pack-per-frame kernels; six calls of one
+    frame each go through the one-wavefront-per-stream kernel with the state carried by the caller.  Same bytes."""
+    import torch
+    pkg = H.pkg()
+    S, F = 8, 6
+    pcm = [H.gen_pcm(F, 6, seed=640 + s, kind=("bursts", "tones", "strobe", "music", "noise", "quiet", "bursts", "tones")[s]) for s in range(S)]
+    desc = pkg.EncodeDesc(48000, 384000, 6)
+    x = torch.from_numpy(np.stack(pcm).reshape(S, F, 1536, 6)).cuda()
+    last = torch.zeros((S, 6, 256), dtype=torch.int16, device="cuda")
+    csnr = torch.full((S,), 40, dtype=torch.int32, device="cuda")
+    whole = engine.encode_batch(desc, x, H.CHMAP6, last, csnr)
+    engine.sync()
+    last1 = torch.zeros((S, 6, 256), dtype=torch.int16, device="cuda")
+    csnr1 = torch.full((S,), 40, dtype=torch.int32, device="cuda")
+    parts = []
+    for f in range(F):
+        parts.append(engine.encode_batch(desc, x[:, f:f + 1].contiguous(), H.CHMAP6, last1, csnr1))
+        engine.sync()
+    step = torch.cat(parts, dim=1)
+    assert torch.equal(whole.cpu(), step.cpu())
+    assert torch.equal(last.cpu(), last1.cpu()) and torch.equal(csnr.cpu(), csnr1.cpu())
+    want, _ = _oracle(pcm, 6, 384000)
+    assert np.array_equal(whole.cpu().numpy()[:, :, :1536], want)
