@@ -830,6 +830,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
 
         const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
         int frame_bits = 0;
+        uint64_t run_starts = 0, row_set = 0;
         bool loaded = false;
         auto load_frame = [&]() {
             loaded = true;
@@ -880,6 +881,15 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                 L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
             }
             WAVE_SYNC();
+            // bit 8*ch + b: block b sends new exponents for channel ch; rows (blk * 6 + ch) that start a run, as a bit set
+            run_starts = row_set = 0;
+            for (int ch = 0; ch < nch; ch++) {
+                const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
+                run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
+            }
+            for (int ch = 0; ch < nch; ch++)
+                for (int b = 0; b < 6; b++)
+                    if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
         };
         // PART 1 replays the search from tabulated verdicts and needs the frame's data only for a verdict that is missing
         if (PART != 1 || P.tap_strat) load_frame();
@@ -918,15 +928,6 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         auto cost_and_record = [&](const int *so, const int *cand_c, const int *cand_f, int n_cand) {
             if (!loaded) load_frame();
             const int budget = 16 * fs - frame_bits;
-            // bit 8*ch + b: block b sends new exponents for channel ch; rows (blk * 6 + ch) that start a run, as a bit set
-            uint64_t run_starts = 0, row_set = 0;
-            for (int ch = 0; ch < nch; ch++) {
-                const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
-                run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
-            }
-            for (int ch = 0; ch < nch; ch++)
-                for (int b = 0; b < 6; b++)
-                    if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
             uint32_t acc[6][3];
 #pragma unroll
             for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
