@@ -183,6 +183,16 @@ def test_exponent_error_is_reported(engine):
     L.orc_a52_free(st)
 
 
+@pytest.mark.parametrize("acmod,lfe,seed", [(7, 1, 11), (2, 0, 12), (0, 1, 13)])
+def test_damaged_frames_match_liba52_block_by_block(engine, acmod, lfe, seed):
+    """Random bit flips and bursts after the acmod field (tests/fuzz_corrupt.py): same first failing block as the
+    oracle's a52_block, bit-identical coefficient planes before it, zero planes from it on, same dither state."""
+    from tests import fuzz_corrupt
+    bad, failed, _ = fuzz_corrupt.damaged_round(engine, seed, acmod, lfe)
+    assert failed > 5          # the round exercises the error paths at all
+    assert bad == 0
+
+
 def test_large_batch_goes_through_the_chunk_pipeline(engine):
     """>= 16384 frames: ac3mi_decode_batch splits the streams into four chunks and runs each chunk's transform on a
     second HIP stream.  Replicated streams must decode to identical PCM, taps and state whatever chunk they fall in."""
