@@ -174,6 +174,15 @@ def gen_pcm(nframes, nch=6, seed=12345, kind="tones"):
         elif kind == "strobe":
             base = 12000 * np.sin(0.013 * (c + 1) * t) + rng.integers(-3000, 3001, n)
             out[:, c] = base * np.repeat(np.where(np.arange(n // 256) % 2 == 0, 1.0, 1.0 / 64), 256)
+        elif kind == "silence":
+            pass
+        elif kind == "rails":                   # full-scale square waves incl. -32768 (abs(-32768), int16 wrap in the FFT)
+            period = 2 + 3 * c
+            out[:, c] = np.where((np.arange(n) // period) % 2 == 0, 32767, -32768)
+        elif kind == "impulses":                # one full-scale sample every ~300 samples over digital silence
+            out[(np.arange(n) % (293 + 17 * c)) == 5 * c, c] = -32768 if c % 2 else 32767
+        elif kind == "dc":                      # constant full-scale level, a different sign per channel
+            out[:, c] = -32768 if c % 2 else 32767
         else:
             raise ValueError(kind)
     return np.clip(np.round(out), -32768, 32767).astype(np.int16)

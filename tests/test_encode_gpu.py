@@ -154,6 +154,28 @@ def test_encode_second_generation_content(engine, kind):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("kind", ["silence", "rails", "impulses", "dc"])
+@pytest.mark.parametrize("nch,bitrate", [(6, 384000), (2, 192000), (1, 64000)])
+def test_encode_extreme_levels(engine, kind, nch, bitrate):
+    """Digital silence, full-scale squares / DC / impulses including -32768: the corners of the fixed-point transform
+    (int16 wrap in the FFT butterflies, abs(-32768), normalisation shift 0 and 16: ac3enc.cpp:493-611, 1673-1697),
+    exponent 24 everywhere and the SNR-offset search running into both of its ends (:921-967).  Byte-exact, and the
+    frames decode on the GPU to what liba52's restatement makes of them."""
+    chmap = H.CHMAP6 if nch == 6 else tuple(range(8))
+    pcm = [H.gen_pcm(3, nch, seed=70 + s, kind=kind) for s in range(2)]
+    want, wt = _oracle(pcm, nch, bitrate, 48000, chmap)
+    got, gt = _gpu(engine, pcm, nch, bitrate, 48000, chmap)
+    assert np.array_equal(gt["mdct"], wt["mdct"][..., :nch, :]), "mdct_coef"
+    assert np.array_equal(gt["snroffst"], wt["snr"]), (gt["snroffst"].tolist(), wt["snr"].tolist())
+    assert np.array_equal(got, want), "bitstream differs in %d bytes" % int((got != want).sum())
+    from tests import test_decode_gpu as D
+    n, sflags, _, _ = H.pkg().syncinfo(got[0, 0])
+    ref_pcm, _, ref_lfsr, _ = D._oracle_decode_with_taps(got, sflags & 0x1f, 1.0, 0.0)
+    dec, status, _, lfsr = D._gpu_decode(engine, got, sflags & 0x1f, 1.0, 0.0, taps=False)
+    assert (status & 0x1ff).max() == 0 and np.array_equal(lfsr, ref_lfsr)
+    assert H.rms(dec.astype(np.float64) - ref_pcm) <= 1e-6
+
+
 def test_batch_shape_paths_agree(engine):
     """One call with six frames per stream goes through the tabulate / replay / pack-per-frame kernels; six calls of one
     frame each go through the one-wavefront-per-stream kernel with the state carried by the caller.  Same bytes."""
