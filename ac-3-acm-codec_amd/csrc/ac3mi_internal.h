@@ -148,6 +148,7 @@ struct ac3mi_ctx {
     size_t ws_tc_bytes;
     // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
     const int32_t *slots;
+    long long tile_frames;  // workspace bound: batches above this many frames go through in tiles of whole streams (0 = never)
     int decode_mode;        // 0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame
     uint32_t *ws_draws;     // [S][F] draw counts + [S][F] u16 frame-start LFSR states (decode, frame-parallel)
     size_t ws_draws_bytes;

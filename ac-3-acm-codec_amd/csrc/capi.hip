@@ -391,6 +391,7 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->ws_tc_bytes = 0;
     ctx->slots = nullptr;
     ctx->decode_mode = 0;
+    ctx->tile_frames = 131072;
     ctx->ws_draws = nullptr;
     ctx->ws_draws_bytes = 0;
     ctx->ws_coef = nullptr;
@@ -510,6 +511,22 @@ int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
     if (!ctx || mode < 0 || mode > 2) return AC3MI_ERR_ARG;
     ctx->decode_mode = mode;
     return AC3MI_OK;
+}
+
+int ac3mi_set_tile_frames(ac3mi_ctx *ctx, long long frames)
+{
+    if (!ctx || frames < 0) return AC3MI_ERR_ARG;
+    ctx->tile_frames = frames;
+    return AC3MI_OK;
+}
+
+// Streams per tile when a batch of n_streams x frames_per_stream is above the workspace bound, else 0 (no tiling).
+static int tile_streams(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
+{
+    if (!ctx->tile_frames || n_streams < 2 || frames_per_stream < 1) return 0;
+    if ((long long)n_streams * frames_per_stream <= ctx->tile_frames) return 0;
+    const long long g = ctx->tile_frames / frames_per_stream;
+    return (int)(g < 1 ? 1 : g);
 }
 
 // frame-parallel front end for few long streams?  (auto: more than one frame per stream and too few streams to fill
@@ -653,6 +670,21 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         return AC3MI_ERR_ARG;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int g = taps ? 0 : tile_streams(ctx, n_streams, frames_per_stream)) {
+        // bounded workspace: whole streams at a time (streams are independent; state arrays move with them)
+        const int32_t *slots0 = ctx->slots;
+        int rc = AC3MI_OK;
+        for (int s0 = 0; s0 < n_streams && rc == AC3MI_OK; s0 += g) {
+            const int ns = n_streams - s0 < g ? n_streams - s0 : g;
+            const size_t f0 = (size_t)s0 * frames_per_stream;
+            if (slots0) ctx->slots = slots0 + s0;
+            rc = ac3mi_decode_batch(ctx, desc, d_frames + f0 * frame_stride, frame_stride, ns, frames_per_stream,
+                                    slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0,
+                                    d_pcm + f0 * 6 * n_out * 256, d_status + f0, nullptr);
+        }
+        ctx->slots = slots0;
+        return rc;
+    }
     const size_t nfr = (size_t)n_streams * frames_per_stream;
     float *coef = taps && taps->d_coef ? taps->d_coef : nullptr;
     uint8_t *blksw = taps && taps->d_blksw ? taps->d_blksw : nullptr;
@@ -767,6 +799,20 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
             return AC3MI_ERR_ARG;
         }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int g = taps ? 0 : tile_streams(ctx, n_streams, frames_per_stream)) {
+        const int32_t *slots0 = ctx->slots;
+        int rc = AC3MI_OK;
+        for (int s0 = 0; s0 < n_streams && rc == AC3MI_OK; s0 += g) {
+            const int ns = n_streams - s0 < g ? n_streams - s0 : g;
+            const size_t f0 = (size_t)s0 * frames_per_stream;
+            if (slots0) ctx->slots = slots0 + s0;
+            rc = ac3mi_encode_batch(ctx, desc, d_pcm + f0 * 1536 * E.cfg.nch, chmap,
+                                    slots0 ? d_last : d_last + (size_t)s0 * E.cfg.nch * 256, slots0 ? d_csnroffst : d_csnroffst + s0,
+                                    d_frames + f0 * frame_stride, frame_stride, ns, frames_per_stream, nullptr);
+        }
+        ctx->slots = slots0;
+        return rc;
+    }
     const size_t rows = (size_t)n_streams * frames_per_stream * 6 * E.cfg.nch;
     const size_t rows_pad = (rows + 255) & ~(size_t)255;
     // mdct | raw exponents | encoded exponents | masking curves | exp_samples | strategies | exponent bits
@@ -852,6 +898,21 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     for (int i = 0; i < enc->channels; i++)
         if (E.chmap[i] >= enc->channels) { ctx->err = "ac3mi_transcode_batch: chmap entry out of range"; return AC3MI_ERR_ARG; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (const int g = tile_streams(ctx, n_streams, frames_per_stream)) {
+        const int32_t *slots0 = ctx->slots;
+        int rc = AC3MI_OK;
+        for (int s0 = 0; s0 < n_streams && rc == AC3MI_OK; s0 += g) {
+            const int ns = n_streams - s0 < g ? n_streams - s0 : g;
+            const size_t f0 = (size_t)s0 * frames_per_stream;
+            if (slots0) ctx->slots = slots0 + s0;
+            rc = ac3mi_transcode_batch(ctx, dec, enc, d_frames_in + f0 * in_stride, in_stride, ns, frames_per_stream,
+                                       slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0, chmap,
+                                       slots0 ? d_last : d_last + (size_t)s0 * E.cfg.nch * 256, slots0 ? d_csnroffst : d_csnroffst + s0,
+                                       d_frames_out + f0 * out_stride, out_stride, d_status + f0);
+        }
+        ctx->slots = slots0;
+        return rc;
+    }
     const size_t F = (size_t)frames_per_stream, nfr = (size_t)n_streams * F;
     // workspaces: decoder planes, float PCM + s16 PCM, encoder arrays
     { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), nfr * 6 * X.plan.nfchans + 4); if (r != AC3MI_OK) return r; }

@@ -178,6 +178,10 @@ class Engine:
             return out, status, tdict
         return out, status
 
+    def set_tile_frames(self, frames):
+        """Workspace bound: batches above `frames` frames go through in tiles of whole streams (ac3mi_set_tile_frames)."""
+        self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))
+
     def set_decode_mode(self, mode):
         """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))

@@ -233,11 +233,43 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     ok = int((status & 0x1ff).max().item()) == 0
     res["decode"]["all_frames_ok"] = ok
     res["_frames"] = frames[:64].cpu().numpy()          # for the CPU rates beside these legs (dropped from the line)
+    if os.environ.get("AC3MI_BENCH_MILLION") == "1":
+        res["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, frames)
     if dist is None:           # host-side work on up to 16 threads: single-process runs only
         res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
                    "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
     return res
+
+
+def million_stream_transcode(pkg, eng, dev, frames, n_streams=1 << 20, passes=2):
+    """BASELINE configs[4], one GPU's share (8M streams / 8 GPUs): decode -> s16 -> re-encode of 2^20 independent streams,
+    one frame each per pass, state carried from pass to pass.  Only with AC3MI_BENCH_MILLION=1 (takes ~1 s of GPU time
+    and ~30 GB of HBM: frames in/out 3 GB, carry-over state 6.5 GB, the engine's tiled workspace ~20 GB)."""
+    import torch
+    S0, _, fb = frames.shape
+    big = frames.repeat((n_streams + S0 - 1) // S0, 1, 1)[:n_streams].contiguous()
+    enc = pkg.EncodeDesc(48000, 384000, 6)
+    dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=fb)
+    delay = torch.zeros((n_streams, 6, 128), dtype=torch.float32, device=dev)
+    lfsr = torch.ones((n_streams,), dtype=torch.int16, device=dev)
+    last = torch.zeros((n_streams, 6, 256), dtype=torch.int16, device=dev)
+    csnr = torch.full((n_streams,), 40, dtype=torch.int32, device=dev)
+    out = torch.zeros((n_streams, 1, fb), dtype=torch.uint8, device=dev)
+    status = torch.zeros((n_streams, 1), dtype=torch.int32, device=dev)
+    chmap = (0, 2, 1, 4, 5, 3)
+    free0, total = torch.cuda.mem_get_info(dev)
+    torch.cuda.synchronize(dev)
+    eng.transcode_batch(dec, enc, big, delay, lfsr, chmap, last, csnr, out=out, status=status, wait_torch=False)
+    eng.timer_start()
+    for _ in range(passes):
+        eng.transcode_batch(dec, enc, big, delay, lfsr, chmap, last, csnr, out=out, status=status, wait_torch=False)
+    ms = eng.timer_stop() / passes
+    free1, _ = torch.cuda.mem_get_info(dev)
+    ok = int((status & 0x1ff).max().item()) == 0
+    same = bool(torch.equal(out[:S0], out[S0:2 * S0])) if n_streams >= 2 * S0 else None
+    return {"streams": n_streams, "ms_per_pass": ms, "frames_per_s_per_gpu": n_streams / (ms * 1e-3), "all_frames_ok": ok,
+            "replicas_agree_across_tiles": same, "engine_workspace_GB": (free0 - free1) / 1e9, "hbm_total_GB": total / 1e9}
 
 
 def stream_layer_timing(pkg, eng, frames, rounds=3):

@@ -108,6 +108,14 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
  *   0  (default) choose by batch shape. */
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 
+/* Workspace bound (new; results are identical).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
+ * their intermediates (coefficient planes, MDCT coefficients, exponents, PCM between decoder and encoder: 37 / 60 /
+ * 152 KB per frame) in workspaces owned by the context.  A batch of more than `frames` frames goes through in tiles
+ * of whole streams of at most that many frames each (at least one stream), one after the other on the context's
+ * streams, so the workspaces stop growing with the batch: a million-stream call needs its own input, output and state
+ * arrays plus a fixed ~20 GB.  Default 131072; 0 = never tile.  Calls that ask for stage taps are not tiled. */
+int ac3mi_set_tile_frames(ac3mi_ctx *ctx, long long frames);
+
 /* Number of input planes (lfeon + fbw channels of acmod) and of output planes
  * for a descriptor; negative on an invalid combination. */
 int ac3mi_xform_planes(const ac3mi_xform_desc *desc, int *n_in, int *n_out);

@@ -154,7 +154,18 @@ def test_encode_any_chunking(S, pool):
     assert bytes(out) == want
 
 
-def test_many_streams_one_launch_per_round(S, pool):
+@pytest.mark.parametrize("tile", [131072, 2])
+def test_many_streams_one_launch_per_round(S, pool, engine, tile):
+    """tile = 2: the engine's workspace bound (ac3mi_set_tile_frames) forces every batched call of the round into tiles
+    of whole streams, with the state-slot table moving along."""
+    engine.set_tile_frames(tile)
+    try:
+        _many_streams(S, pool)
+    finally:
+        engine.set_tile_frames(131072)
+
+
+def _many_streams(S, pool):
     rng = np.random.default_rng(4)
     kinds = ("tones", "music", "noise", "bursts", "quiet")
     frames = [H.orc_encode(H.gen_pcm(3, 6, seed=100 + i, kind=kinds[i % 5])) for i in range(5)]

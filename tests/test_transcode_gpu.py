@@ -91,3 +91,46 @@ def test_transcode_against_the_oracle_chain(engine):
         noise_g = H.rms(np.moveaxis(got_pcm, 2, 0).reshape(6, -1)[:, 256:] - a)
         noise_r = H.rms(np.moveaxis(ref_pcm, 2, 0).reshape(6, -1)[:, 256:] - a)
         assert noise_g <= 1.1 * noise_r + 1e-6, (noise_g, noise_r)
+
+
+@pytest.mark.parametrize("tile", [4, 7, 30])
+def test_workspace_tiles_do_not_change_anything(engine, tile):
+    """ac3mi_set_tile_frames: a batch above the bound goes through in tiles of whole streams (tile 4 with F = 3: one
+    stream at a time; 7: two streams; 30: ten).  Decode, encode and transcode must give the bytes, PCM and carry-over
+    state of the untiled call."""
+    import torch
+    pkg = H.pkg()
+    S, F = 23, 3
+    kinds = ("tones", "music", "bursts", "noise", "quiet", "strobe")
+    streams = np.stack([H.orc_encode(H.gen_pcm(F, 6, seed=900 + s, kind=kinds[s % 6])) for s in range(S)])
+    frames_t = torch.from_numpy(streams).cuda()
+    pcm_in = torch.from_numpy(np.stack([H.gen_pcm(F, 6, seed=950 + s, kind=kinds[(s + 2) % 6]) for s in range(S)]).reshape(S, F, 1536, 6)).cuda()
+    dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=streams.shape[2])
+    enc = pkg.EncodeDesc(48000, 384000, 6)
+
+    def run():
+        dev = frames_t.device
+        delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+        lfsr = torch.ones((S,), dtype=torch.int16, device=dev)
+        pcm, st = engine.decode_batch(dec, frames_t, delay, lfsr)
+        last = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+        csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
+        fr = engine.encode_batch(enc, pcm_in, H.CHMAP6, last, csnr)
+        delay2 = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+        lfsr2 = torch.ones((S,), dtype=torch.int16, device=dev)
+        last2 = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+        csnr2 = torch.full((S,), 40, dtype=torch.int32, device=dev)
+        out, st2 = engine.transcode_batch(dec, enc, frames_t, delay2, lfsr2, H.CHMAP6, last2, csnr2)
+        engine.sync()
+        return [t.cpu() for t in (pcm, st, delay, lfsr, fr, last, csnr, out, st2, delay2, lfsr2, last2, csnr2)]
+
+    engine.set_tile_frames(0)
+    want = run()
+    try:
+        engine.set_tile_frames(tile)
+        got = run()
+    finally:
+        engine.set_tile_frames(131072)
+    names = "pcm status delay lfsr frames last csnr tc_frames tc_status tc_delay tc_lfsr tc_last tc_csnr".split()
+    for n, g, w in zip(names, got, want):
+        assert torch.equal(g, w), n
