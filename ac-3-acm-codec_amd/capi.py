@@ -98,6 +98,8 @@ def load_library():
     lib.ac3mi_decode_planes.argtypes = [ctypes.POINTER(DecodeDescC), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     lib.ac3mi_decode_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(DecodeTapsC)]
+    lib.ac3mi_decode_s16_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]
     lib.ac3mi_encode_frame_bytes.argtypes = [ctypes.POINTER(EncodeDescC)]
     lib.ac3mi_encode_tables.argtypes = [c_void_p] * 5
     lib.ac3mi_encode_batch.argtypes = [c_void_p, ctypes.POINTER(EncodeDescC), c_void_p, c_void_p, c_void_p, c_void_p,

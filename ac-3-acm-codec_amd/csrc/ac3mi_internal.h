@@ -67,6 +67,10 @@ struct XformLaunch {
     MixPlan plan;
     const int32_t *slot;    // optional per-stream state slot indices (device), see ac3mi_set_state_slots
     int delay_stride;
+    // s16 output instead of float planes: [n_streams][frames][6][256][n_out] interleaved in WAVE channel order, what the
+    // reference's MapTab converters make of a52_samples() at bias 384 (src/AC3ASM.asm; s16_channel_map).  pcm is unused then.
+    int16_t *pcm16 = nullptr;
+    int s16_flags = 0;      // liba52 output flags of the planes (selects the channel order)
 };
 
 // a52_downmix()/a52_downmix_init() semantics as a plane-mixing matrix; returns <0 if
@@ -148,6 +152,7 @@ struct ac3mi_ctx {
     size_t ws_tc_bytes;
     // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
     const int32_t *slots;
+    bool no_overlap;        // AC3MI_NO_OVERLAP in the environment: no chunk pipelines (clean per-kernel profiles)
     long long tile_frames;  // workspace bound: batches above this many frames go through in tiles of whole streams (0 = never)
     int decode_mode;        // 0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame
     uint32_t *ws_draws;     // [S][F] draw counts + [S][F] u16 frame-start LFSR states (decode, frame-parallel)

@@ -392,6 +392,7 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->slots = nullptr;
     ctx->decode_mode = 0;
     ctx->tile_frames = 131072;
+    ctx->no_overlap = getenv("AC3MI_NO_OVERLAP") != nullptr;     // profiling aid: one chunk, one stream, kernels back to back
     ctx->ws_draws = nullptr;
     ctx->ws_draws_bytes = 0;
     ctx->ws_coef = nullptr;
@@ -648,12 +649,13 @@ static int ensure_ws(ac3mi_ctx *ctx, size_t coef_bytes, size_t blksw_bytes)
     return AC3MI_OK;
 }
 
-int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+// d_pcm (float planes) or d_pcm16 (interleaved s16, written by the transform itself)
+static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
                        int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
-                       uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status, const ac3mi_decode_taps *taps)
+                       uint16_t *d_lfsr, float *d_pcm, int16_t *d_pcm16, uint32_t *d_status, const ac3mi_decode_taps *taps)
 {
     if (!ctx) return AC3MI_ERR_ARG;
-    if (!desc || !d_frames || !d_delay || !d_lfsr || !d_pcm || !d_status || n_streams < 0 ||
+    if (!desc || !d_frames || !d_delay || !d_lfsr || (!d_pcm && !d_pcm16) || !d_status || n_streams < 0 ||
         frames_per_stream < 0 || desc->frame_bytes < 8 || desc->frame_bytes > 3840 ||
         frame_stride < ((desc->frame_bytes + 3) & ~3) || (frame_stride & 3) || ((uintptr_t)d_frames & 3)) {
         ctx->err = "ac3mi_decode_batch: bad argument";
@@ -678,9 +680,10 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
             const int ns = n_streams - s0 < g ? n_streams - s0 : g;
             const size_t f0 = (size_t)s0 * frames_per_stream;
             if (slots0) ctx->slots = slots0 + s0;
-            rc = ac3mi_decode_batch(ctx, desc, d_frames + f0 * frame_stride, frame_stride, ns, frames_per_stream,
-                                    slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0,
-                                    d_pcm + f0 * 6 * n_out * 256, d_status + f0, nullptr);
+            rc = decode_impl(ctx, desc, d_frames + f0 * frame_stride, frame_stride, ns, frames_per_stream,
+                             slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0,
+                             d_pcm ? d_pcm + f0 * 6 * n_out * 256 : nullptr, d_pcm16 ? d_pcm16 + f0 * 6 * n_out * 256 : nullptr,
+                             d_status + f0, nullptr);
         }
         ctx->slots = slots0;
         return rc;
@@ -700,7 +703,7 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // A large batch goes through in four chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 4 : 1;       // measured: 4.79 -> 4.66 ms on 65536 frames
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 4 : 1;       // measured: 4.79 -> 4.66 ms on 65536 frames
     const size_t F = (size_t)frames_per_stream;
     for (int k = 0; k < n_chunks; k++) {
         const int s0 = (int)((long long)n_streams * k / n_chunks), s1 = (int)((long long)n_streams * (k + 1) / n_chunks);
@@ -741,7 +744,9 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         X.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * X.plan.n_out * 128;
         X.slot = D.slot;
         X.delay_stride = 6 * 128;
-        X.pcm = d_pcm + f0 * 6 * X.plan.n_out * 256;
+        X.pcm = d_pcm ? d_pcm + f0 * 6 * X.plan.n_out * 256 : nullptr;
+        X.pcm16 = d_pcm16 ? d_pcm16 + f0 * 6 * X.plan.n_out * 256 : nullptr;
+        X.s16_flags = out_flags;
         X.n_streams = ns;
         X.frames = frames_per_stream;
         X.bias = desc->bias;
@@ -752,6 +757,32 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     return AC3MI_OK;
+}
+
+int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+                       int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
+                       uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status, const ac3mi_decode_taps *taps)
+{
+    if (ctx && !d_pcm) {
+        ctx->err = "ac3mi_decode_batch: bad argument";
+        return AC3MI_ERR_ARG;
+    }
+    return decode_impl(ctx, desc, d_frames, frame_stride, n_streams, frames_per_stream, d_delay, d_lfsr, d_pcm, nullptr, d_status, taps);
+}
+
+int ac3mi_decode_s16_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+                           int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
+                           uint16_t *d_lfsr, int16_t *d_pcm16, uint32_t *d_status)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    if (!desc || !d_pcm16 || ((uintptr_t)d_pcm16 & 15)) {
+        ctx->err = "ac3mi_decode_s16_batch: bad argument (d_pcm16 must be 16-byte aligned)";
+        return AC3MI_ERR_ARG;
+    }
+    ac3mi_decode_desc dd = *desc;
+    dd.level = 1.0f;                                    // what the reference's converters presuppose (src/AC3ACM.cpp:1553)
+    dd.bias = 384.0f;
+    return decode_impl(ctx, &dd, d_frames, frame_stride, n_streams, frames_per_stream, d_delay, d_lfsr, nullptr, d_pcm16, d_status, nullptr);
 }
 
 int ac3mi_encode_frame_bytes(const ac3mi_encode_desc *desc)
@@ -916,17 +947,16 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     const size_t F = (size_t)frames_per_stream, nfr = (size_t)n_streams * F;
     // workspaces: decoder planes, float PCM + s16 PCM, encoder arrays
     { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), nfr * 6 * X.plan.nfchans + 4); if (r != AC3MI_OK) return r; }
-    const size_t pcm_bytes = nfr * 6 * n_out * 256 * sizeof(float), s16_bytes = nfr * 1536 * n_out * 2;
-    if (pcm_bytes + s16_bytes + 512 > ctx->ws_tc_bytes) {
+    const size_t s16_bytes = nfr * 1536 * n_out * 2;       // the transform writes s16 itself: no float PCM in between
+    if (s16_bytes + 512 > ctx->ws_tc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_tc);
         ctx->ws_tc = nullptr;
         ctx->ws_tc_bytes = 0;
-        HIPCHK(ctx, hipMalloc(&ctx->ws_tc, pcm_bytes + s16_bytes + 512));
-        ctx->ws_tc_bytes = pcm_bytes + s16_bytes + 512;
+        HIPCHK(ctx, hipMalloc(&ctx->ws_tc, s16_bytes + 512));
+        ctx->ws_tc_bytes = s16_bytes + 512;
     }
-    float *ws_pcm = (float *)ctx->ws_tc;
-    int16_t *ws_s16 = (int16_t *)((uint8_t *)ctx->ws_tc + ((pcm_bytes + 255) & ~(size_t)255));
+    int16_t *ws_s16 = (int16_t *)ctx->ws_tc;
     const size_t rows = nfr * 6 * E.cfg.nch, rows_pad = (rows + 255) & ~(size_t)255;
     const size_t off_eexp = rows * 256 * 4 + rows * 256, off_emask = off_eexp + rows * 256;
     const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
@@ -943,7 +973,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 ? 2 : 1;       // measured on 65536 frames: 13.0 (1), 12.7 (2), 12.75 ms (4)
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames: 13.0 (1), 12.7 (2), 12.75 ms (4)
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
@@ -980,13 +1010,13 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         Y.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * n_out * 128;
         Y.slot = ctx->slots ? ctx->slots + s0 : nullptr;
         Y.delay_stride = 6 * 128;
-        Y.pcm = ws_pcm + f0 * 6 * n_out * 256;
+        Y.pcm = nullptr;
+        Y.pcm16 = ws_s16 + f0 * 1536 * n_out;
+        Y.s16_flags = out_flags;
         Y.n_streams = ns;
         Y.frames = frames_per_stream;
         Y.bias = 384.0f;
-        hipError_t e = launch_xform(ctx->tab, Y, st);
-        if (e != hipSuccess) return e;
-        return launch_convert_s16(Y.pcm, ws_s16 + f0 * 1536 * n_out, out_flags, (size_t)ns * F * 6, st);
+        return launch_xform(ctx->tab, Y, st);
     };
     auto back = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;

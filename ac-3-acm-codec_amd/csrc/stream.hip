@@ -117,7 +117,6 @@ struct ac3mi_pool {
     // per-round staging (device / pinned host), one entry per stream taking part in the round
     int32_t *d_slots, *h_slots;
     uint8_t *d_frames, *h_frames;       // [cap][FRAME_STRIDE]
-    float *d_pcm;                       // [cap][6][6][256]
     int16_t *d_s16, *h_s16;             // [cap][6][256][6]  (decode out)  /  [cap][1536][6] (encode in)
     uint32_t *d_status, *h_status;      // [cap]
 };
@@ -339,10 +338,9 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
     ac3mi_ctx *ctx = p->ctx;
     int32_t *d_slots = p->d_slots + base, *h_slots = p->h_slots + base;
     uint8_t *d_frames = p->d_frames + (size_t)base * FRAME_STRIDE, *h_frames = p->h_frames + (size_t)base * FRAME_STRIDE;
-    float *d_pcm = p->d_pcm + (size_t)base * 6 * 6 * 256;
     int16_t *d_s16 = (int16_t *)((uint8_t *)p->d_s16 + (size_t)base * PCM_FRAME_BYTES), *h_s16 = (int16_t *)((uint8_t *)p->h_s16 + (size_t)base * PCM_FRAME_BYTES);
     uint32_t *d_status = p->d_status + base, *h_status = p->h_status + base;
-    (void)d_pcm; (void)d_status; (void)h_status;
+    (void)d_status; (void)h_status;
     const int k = (int)group.size();
     const ac3mi_stream *s0 = group[0];
     ac3mi_decode_desc d;
@@ -368,8 +366,7 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
     if (ac3mi_memcpy_h2d(ctx, d_slots, h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_memcpy_h2d(ctx, d_frames, h_frames, (size_t)k * FRAME_STRIDE) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     ac3mi_set_state_slots(ctx, d_slots);
-    int rc = ac3mi_decode_batch(ctx, &d, d_frames, FRAME_STRIDE, k, 1, p->d_delay, p->d_lfsr, d_pcm, d_status, NULL);
-    if (rc == AC3MI_OK) rc = ac3mi_convert_s16_batch(ctx, d_pcm, d_s16, granted, (size_t)k * 6);
+    int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames, FRAME_STRIDE, k, 1, p->d_delay, p->d_lfsr, d_s16, d_status);
     ac3mi_set_state_slots(ctx, NULL);
     if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch");
     const size_t blk = (size_t)256 * n_out * 2;
@@ -390,10 +387,9 @@ int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
     ac3mi_ctx *ctx = p->ctx;
     int32_t *d_slots = p->d_slots + base, *h_slots = p->h_slots + base;
     uint8_t *d_frames = p->d_frames + (size_t)base * FRAME_STRIDE, *h_frames = p->h_frames + (size_t)base * FRAME_STRIDE;
-    float *d_pcm = p->d_pcm + (size_t)base * 6 * 6 * 256;
     int16_t *d_s16 = (int16_t *)((uint8_t *)p->d_s16 + (size_t)base * PCM_FRAME_BYTES), *h_s16 = (int16_t *)((uint8_t *)p->h_s16 + (size_t)base * PCM_FRAME_BYTES);
     uint32_t *d_status = p->d_status + base, *h_status = p->h_status + base;
-    (void)d_pcm; (void)d_status; (void)h_status;
+    (void)d_status; (void)h_status;
     const int k = (int)group.size();
     const ac3mi_stream *s0 = group[0];
     const int nch = s0->src.channels;
@@ -446,7 +442,6 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
     p->d_csnr = (int32_t *)dev(n * 4);
     p->d_slots = (int32_t *)dev(n * 4);
     p->d_frames = (uint8_t *)dev(n * FRAME_STRIDE);
-    p->d_pcm = (float *)dev(n * 6 * 6 * 256 * 4);
     p->d_s16 = (int16_t *)dev(n * PCM_FRAME_BYTES);
     p->d_status = (uint32_t *)dev(n * 4);
     p->h_slots = (int32_t *)pin(n * 4);
@@ -471,7 +466,7 @@ void ac3mi_pool_destroy(ac3mi_pool *p)
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)ac3mi_sync(p->ctx);
-    void *dv[] = {p->d_delay, p->d_lfsr, p->d_last, p->d_csnr, p->d_slots, p->d_frames, p->d_pcm, p->d_s16, p->d_status};
+    void *dv[] = {p->d_delay, p->d_lfsr, p->d_last, p->d_csnr, p->d_slots, p->d_frames, p->d_s16, p->d_status};
     for (void *q : dv) if (q) ac3mi_dev_free(p->ctx, q);
     void *hv[] = {p->h_slots, p->h_frames, p->h_s16, p->h_status};
     for (void *q : hv) if (q) (void)hipHostFree(q);

@@ -12,6 +12,10 @@
 // HBM traffic per channel-block: 1 KiB coefficients in (x number of mixed input
 // planes), 1 KiB PCM out; all accesses are 8 B per lane, 64 B contiguous per group.
 // LDS: one 8x16 complex transpose per transform (1216 B per group, padded rows).
+//
+// S16 variants: the reference's float -> s16 converter (src/AC3ASM.asm:174-318) folded into the
+// output stage; a wavefront carries whole streams and writes interleaved 16-bit samples, see
+// XformParams::pcm16.
 #include "ac3mi_internal.h"
 #include "xform_core.h"
 
@@ -33,9 +37,24 @@ struct XformParams {
     const int32_t *slot;        // optional: stream s keeps its overlap state in slot[s]
     int delay_stride;           // floats per state slot (n_out * 128 without slots)
     // few long streams: a chain is cut into n_seg segments of seg_blocks blocks, one 8-lane group each.  A block's
-    // overlap tail depends on the block before it only, so a segment first re-derives the tail of the block ahead of it.
+    // overlap tail depends on the block before it only, so a segment first re-derives the tail of the block ahead of it
+    // (and segment 0 the tail of the chain's last block, which it writes back as the new state).
     int n_seg, seg_blocks;
+    // S16 kernels: interleaved 16-bit output, plane o goes to WAVE slot wslot[o].  A wavefront then carries whole
+    // streams (gps of them, n_out groups each; left-over groups shadow group 0 without storing anything), gathers a
+    // block's samples in LDS and writes them out 16 bytes per lane.
+    int16_t *pcm16;
+    int8_t wslot[6];
+    int n_streams, gps;
 };
+
+// what the reference's converters make of a float sample at bias 384 (src/AC3ASM.asm:303-318: psubd, packssdw)
+__device__ __forceinline__ int16_t to_s16(float v)
+{
+    int i = (int)(__float_as_uint(v) - 0x43c00000u);
+    i = i > 32767 ? 32767 : i < -32768 ? -32768 : i;
+    return (int16_t)i;
+}
 
 // long-block input pattern: lane l8 owns m = 8*n1 + l8
 __device__ __forceinline__ void load_long(const float *plane, int l8, float sign, float (&xa)[16], float (&xb)[16])
@@ -64,7 +83,7 @@ __device__ __forceinline__ void load_short(const float *plane, int l8, float sig
     }
 }
 
-template <bool MIX, int WPS>
+template <bool MIX, int WPS, bool S16 = false>
 __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 {
     __shared__ float2 lds_ex[4 * EX_WAVE];
@@ -74,13 +93,25 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     const int tid = threadIdx.x;
     const int l8 = tid & 7;
     const int group = tid >> 3;                     // 0..31 inside the workgroup
-    const int vchain = blockIdx.x * 32 + group;     // (chain, segment)
-    const int chain = vchain / P.n_seg, seg = vchain - chain * P.n_seg;
+    int chain, seg, pack = 0, sl = 0;
+    bool active = true;
+    if (!S16) {
+        const int vchain = blockIdx.x * 32 + group; // (chain, segment)
+        chain = vchain / P.n_seg;
+        seg = vchain - chain * P.n_seg;
+    } else {
+        const int unit = blockIdx.x * 4 + (tid >> 6);       // (pack of gps streams, segment) per wavefront
+        pack = unit / P.n_seg;
+        seg = unit - pack * P.n_seg;
+        sl = (group & 7) / P.n_out;
+        active = sl < P.gps && pack * P.gps + sl < P.n_streams;
+        chain = active ? (pack * P.gps + sl) * P.n_out + ((group & 7) - sl * P.n_out) : pack * P.gps * P.n_out;
+    }
     // constants shared by the whole workgroup live in LDS (registers are the scarce resource here)
     if (tid < 128) lds_twl[tid] = P.tw_long[tid];
     lds_win[tid] = P.window[tid];
     __syncthreads();
-    if (chain >= P.n_chains) return;                // whole 8-lane groups leave together (chain = vchain / n_seg)
+    if (chain >= P.n_chains) return;                // whole 8-lane groups leave together (S16: whole wavefronts)
     float2 *ex = lds_ex + group * EX_GROUP;
     const float2 *twl = lds_twl + l8 * 16;
 
@@ -98,13 +129,23 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     const size_t in_stride_blk = (size_t)P.n_in * 256;
     const size_t out_stride_blk = (size_t)P.n_out * 256;
     const float *cbase = P.coef + (size_t)s * P.frames * 6 * in_stride_blk;
-    float *obase = P.pcm + (size_t)s * P.frames * 6 * out_stride_blk + (size_t)o * 256;
+    float *obase = S16 ? nullptr : P.pcm + (size_t)s * P.frames * 6 * out_stride_blk + (size_t)o * 256;
     const uint8_t *swbase = P.blksw ? P.blksw + (size_t)s * P.frames * 6 * P.nfchans : nullptr;
+    int16_t *tile = reinterpret_cast<int16_t *>(lds_ex + (tid >> 6) * EX_WAVE);       // free between two transforms
+    const int tbase = sl * 256 * P.n_out + P.wslot[o];
 
     const int nblk = P.frames * 6;
     const int b_lo = seg * P.seg_blocks, b_hi = b_lo + P.seg_blocks < nblk ? b_lo + P.seg_blocks : nblk;
-    for (int b = seg ? b_lo - 1 : b_lo; b < b_hi; b++) {
-        const bool emit = b >= b_lo;                // the block ahead of a segment only supplies its tail
+    // The overlap state is read and rewritten in place, and the segments of a chain run in groups (possibly workgroups)
+    // of their own with nothing ordering them: so the group that READS the chain's state (segment 0) is also the one
+    // that writes it back - it transforms the chain's last block once more for its tail (which depends on that block's
+    // coefficients only).  The last segment never touches the state.
+    const bool tail_pass = P.n_seg > 1 && seg == 0;
+    const int b_first = seg ? b_lo - 1 : b_lo, n_iter = b_hi - b_first + (tail_pass ? 1 : 0);
+    for (int it = 0; it < n_iter; it++) {
+        const bool extra = tail_pass && it == n_iter - 1;
+        const int b = extra ? nblk - 1 : b_first + it;
+        const bool emit = !extra && b >= b_lo;      // the block ahead of a segment only supplies its tail
         const float *cblk = cbase + (size_t)b * in_stride_blk;
         FirstTail ft;
 #pragma unroll
@@ -164,7 +205,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
         }
 
         // window + overlap-add + bias, then the new tail
-        float *oblk = obase + (size_t)b * out_stride_blk;
+        float *oblk = S16 ? nullptr : obase + (size_t)b * out_stride_blk;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
@@ -175,16 +216,39 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             lo.y = ft.f1[j] * wlo.y + (dl[j].y * whi.x + P.bias);          // out[2i+1]
             hi.x = dl[j].y * wlo.y + P.bias - ft.f1[j] * whi.x;            // out[254-2i]
             hi.y = dl[j].x * wlo.x + P.bias - ft.f0[j] * whi.y;            // out[255-2i]
-            if (emit) {
+            if (emit && !S16) {
                 *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
                 *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
+            }
+            if (S16 && emit && active) {
+                tile[tbase + (2 * i) * P.n_out] = to_s16(lo.x);
+                tile[tbase + (2 * i + 1) * P.n_out] = to_s16(lo.y);
+                tile[tbase + (254 - 2 * i) * P.n_out] = to_s16(hi.x);
+                tile[tbase + (255 - 2 * i) * P.n_out] = to_s16(hi.y);
             }
             dl[j].x = ft.t0[j];
             dl[j].y = ft.t1[j];
         }
+        if (S16 && emit) {                          // wave-uniform: a wavefront's groups share the segment
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int upb = 32 * P.n_out;           // 16-byte units per stream-block
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int u = it * 64 + (tid & 63);
+                const int su = u / upb, stream = pack * P.gps + su;
+                if (su < P.gps && stream < P.n_streams) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(tile + u * 8);
+                    *reinterpret_cast<uint4 *>(P.pcm16 + ((size_t)stream * P.frames * 6 + b) * out_stride_blk + (size_t)(u - su * upb) * 8) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 
-    if (b_hi == nblk) {
+    if (seg == 0 && active) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
@@ -229,10 +293,24 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
         P.seg_blocks = frames_per_seg * 6;
     }
     if (P.n_seg == 1) P.seg_blocks = P.frames * 6;
-    const int grid = (int)(((long long)P.n_chains * P.n_seg + 31) / 32);
+    int grid = (int)(((long long)P.n_chains * P.n_seg + 31) / 32);
+    P.n_streams = L.n_streams;
+    P.gps = 8 / P.n_out;
+    if (L.pcm16) grid = (int)((((long long)(L.n_streams + P.gps - 1) / P.gps) * P.n_seg + 3) / 4);
     // 4 workgroups per CU (LDS: 40 KB each); measured on MI355X: 3 vs 4 waves/SIMD, packed vs scalar f32 and
     // 8- vs 16-byte accesses all land within 1 % - the kernel runs at the rate of a plain copy with the same
     // addressing (profiles/r01_xform_probes.md)
+    P.pcm16 = L.pcm16;
+    if (L.pcm16) {
+        int map[6];
+        if (s16_channel_map(L.s16_flags, map) != P.n_out || ((uintptr_t)L.pcm16 & 15)) return hipErrorInvalidValue;
+        for (int w = 0; w < P.n_out; w++) P.wslot[map[w]] = (int8_t)w;
+        if (identity)
+            hipLaunchKernelGGL((xform_kernel<false, 3, true>), dim3(grid), dim3(256), 0, stream, P);
+        else
+            hipLaunchKernelGGL((xform_kernel<true, 2, true>), dim3(grid), dim3(256), 0, stream, P);
+        return hipGetLastError();
+    }
     if (identity)
         hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, P);
     else

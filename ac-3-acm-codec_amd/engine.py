@@ -178,6 +178,28 @@ class Engine:
             return out, status, tdict
         return out, status
 
+    def decode_s16_batch(self, desc, frames, delay, lfsr, out=None, status=None, wait_torch=True):
+        """ac3mi_decode_s16_batch: like decode_batch at level 1 / bias 384 with the reference's s16 converter folded into
+        the transform -> (pcm [S][F][6][256][n_out] i16 in WAVE channel order, status [S][F] i32)."""
+        import torch
+        if wait_torch:
+            torch.cuda.synchronize(self.device)
+        n_out, _ = self.decode_planes(desc)
+        S, F, stride = frames.shape
+        assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.is_cuda
+        assert delay.dtype == torch.float32 and tuple(delay.shape) == (S, n_out, 128) and delay.is_contiguous()
+        assert lfsr.dtype in (torch.int16, torch.uint16) and tuple(lfsr.shape) == (S,)
+        dev = frames.device
+        if out is None:
+            out = torch.empty((S, F, 6, 256, n_out), dtype=torch.int16, device=dev)
+        if status is None:
+            status = torch.zeros((S, F), dtype=torch.int32, device=dev)
+        c = desc.c()
+        self._check(self.lib.ac3mi_decode_s16_batch(self.ctx, ctypes.byref(c), frames.data_ptr(), stride, S, F,
+                                                    delay.data_ptr(), lfsr.data_ptr(), out.data_ptr(), status.data_ptr()))
+        self._keep.append((frames, delay, lfsr, out, status))
+        return out, status
+
     def set_tile_frames(self, frames):
         """Workspace bound: batches above `frames` frames go through in tiles of whole streams (ac3mi_set_tile_frames)."""
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))

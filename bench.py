@@ -198,6 +198,11 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     def do_dec():
         eng.decode_batch(dec, frames, delay, lfsr, out=out, status=status, wait_torch=False)
 
+    out16 = torch.empty((S, 1, 6, 256, 6), dtype=torch.int16, device=dev)
+
+    def do_dec16():
+        eng.decode_s16_batch(dec, frames, delay, lfsr, out=out16, status=status, wait_torch=False)
+
     def do_cvt():
         eng._check(eng.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(eng.ctx), ctypes.c_void_p(out.data_ptr()),
                                                   ctypes.c_void_p(s16.data_ptr()), 7 | 16, ctypes.c_size_t(S * 6)))
@@ -213,6 +218,7 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     res = {}
     for name, fn, nbytes in (("encode", do_enc, 18432 + 1536 + 2 * 3072),
                              ("decode", do_dec, 1536 + 36864 + 2 * 3072),
+                             ("decode_s16", do_dec16, 1536 + 18432 + 2 * 3072),
                              ("transcode", do_transcode, 38400 + 19968)):
         torch.cuda.synchronize(dev)
         fn()

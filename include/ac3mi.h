@@ -198,6 +198,17 @@ int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
                        uint16_t *d_lfsr, float *d_pcm, uint32_t *d_status,
                        const ac3mi_decode_taps *taps);
 
+/* The same with the reference's PCM converter folded in (new): what the ACM driver's decode loop hands to the client,
+ *   a52_frame(level 1, bias 384) -> 6 x (a52_block -> MapTab[..][..][..](a52_samples(), dst, flags))
+ * (src/AC3ACM.cpp:1553-1581; converters src/AC3ASM.asm:174-318, saturating as the x64 build's).  desc->level and
+ * desc->bias are ignored (1 and 384 are what the converters presuppose).
+ * d_pcm16  [n_streams][frames_per_stream][6][256][n_out] s16 (16-byte aligned), channels interleaved in WAVE order
+ *          (ac3mi_convert_s16_batch's layout; bit-identical to ac3mi_decode_batch + ac3mi_convert_s16_batch, without
+ *          the float planes going through HBM) */
+int ac3mi_decode_s16_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,
+                           int frame_stride, int n_streams, int frames_per_stream, float *d_delay,
+                           uint16_t *d_lfsr, int16_t *d_pcm16, uint32_t *d_status);
+
 /* ---- float -> s16 conversion --------------------------------------------------- */
 
 /* Replaces the MMX converters of src/AC3ASM.asm (mmx_convert_N_to_N: psubd 0x43C00000 + packssdw,
@@ -256,9 +267,9 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
 /* BASELINE configs[4]: decode -> s16 -> re-encode for a batch of independent streams in one call (what a host does
  * with stream_convert_ac3 followed by stream_convert_pcm, src/AC3ACM.cpp:1498-1581, 1762).  Equivalent to
  * ac3mi_decode_batch (level 1, bias 384; dec->level / dec->bias are ignored) + ac3mi_convert_s16_batch +
- * ac3mi_encode_batch with the same state arrays, bit for bit; the float and s16 PCM stay in the engine's
- * workspace, and for large batches the HBM-bound transform / conversion kernels of one chunk of streams run on a
- * second stream under the instruction-bound front end and encoder of its neighbours.
+ * ac3mi_encode_batch with the same state arrays, bit for bit; the transform writes the s16 PCM itself, into the
+ * engine's workspace (no float PCM in between), and for large batches the HBM-bound transform of one chunk of
+ * streams runs on a second stream under the instruction-bound front end and encoder of its neighbours.
  * The decoder's output channel count (ac3mi_decode_planes) must equal enc->channels; chmap as in
  * ac3mi_encode_batch, applied to the WAVE-order s16 frames. */
 int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac3mi_encode_desc *enc,

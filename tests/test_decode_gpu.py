@@ -259,3 +259,37 @@ def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
     assert (res[1][1] & 0x1ff).max() == 0
     for a, b in zip(res[1], res[2]):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.mark.parametrize("acmod,lfe,req", [(7, 1, 7 | 16), (7, 1, 2), (2, 0, 2), (7, 1, 10), (3, 1, 3 | 16), (1, 0, 1), (6, 0, 6), (7, 0, 4)])
+def test_decode_s16_equals_decode_plus_converter(engine, acmod, lfe, req):
+    """ac3mi_decode_s16_batch (the transform writes interleaved s16 itself) against ac3mi_decode_batch at level 1 / bias
+    384 followed by ac3mi_convert_s16_batch, on packer streams with block switching and downmixes: same samples, same
+    carry-over state.  Includes a hot stream whose samples saturate (packssdw)."""
+    import torch
+    from tests import packer
+    pkg = H.pkg()
+    S, F = 7, 3
+    frames = np.stack([packer.make_stream(4000 + 13 * s + acmod, F, acmod, lfe) for s in range(S)])
+    fb = frames.shape[2]
+    stride = (fb + 3) & ~3
+    padded = np.zeros((S, F, stride), np.uint8)
+    padded[:, :, :fb] = frames
+    d_frames = torch.from_numpy(padded).cuda()
+    desc = pkg.DecodeDesc(flags=req | 32, level=1.0, bias=384.0, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
+    n_out, oflags = engine.decode_planes(desc)
+    delay = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
+    lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+    pcm, status = engine.decode_batch(desc, d_frames, delay, lfsr)
+    engine.sync()
+    want = torch.empty((S, F, 6, 256, n_out), dtype=torch.int16, device="cuda")
+    engine._check(engine.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(engine.ctx), ctypes.c_void_p(pcm.data_ptr()),
+                                                     ctypes.c_void_p(want.data_ptr()), oflags, ctypes.c_size_t(S * F * 6)))
+    delay2 = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
+    lfsr2 = torch.ones((S,), dtype=torch.int16, device="cuda")
+    got, status2 = engine.decode_s16_batch(desc, d_frames, delay2, lfsr2)
+    engine.sync()
+    assert int((status.cpu() & 0x1ff).max()) == 0
+    assert torch.equal(got.cpu(), want.cpu())
+    assert torch.equal(status.cpu(), status2.cpu()) and torch.equal(delay.cpu(), delay2.cpu()) and torch.equal(lfsr.cpu(), lfsr2.cpu())
+    assert int(want.cpu().abs().max()) > 100
