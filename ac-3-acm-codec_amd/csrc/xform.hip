@@ -132,7 +132,26 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     float *obase = S16 ? nullptr : P.pcm + (size_t)s * P.frames * 6 * out_stride_blk + (size_t)o * 256;
     const uint8_t *swbase = P.blksw ? P.blksw + (size_t)s * P.frames * 6 * P.nfchans : nullptr;
     int16_t *tile = reinterpret_cast<int16_t *>(lds_ex + (tid >> 6) * EX_WAVE);       // free between two transforms
-    const int tbase = sl * 256 * P.n_out + P.wslot[o];
+    int wsl = 0;
+#pragma unroll
+    for (int oo = 0; oo < 6; oo++) wsl = oo == o ? P.wslot[oo] : wsl;      // (no per-lane indexing of kernel arguments)
+    const int tbase = sl * 256 * P.n_out + wsl;
+    // MIX: the input planes of this output as a packed list (3 bits each) with their signs
+    uint32_t plist = 0, psign = 0;
+    int pcnt = 0;
+    if (MIX) {
+#pragma unroll
+        for (int oo = 0; oo < 6; oo++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int m = P.mix[oo][c];
+                if (oo == o && c < P.n_in && m) {
+                    plist |= (uint32_t)c << (3 * pcnt);
+                    psign |= (m < 0 ? 1u : 0u) << pcnt;
+                    pcnt++;
+                }
+            }
+    }
 
     const int nblk = P.frames * 6;
     const int b_lo = seg * P.seg_blocks, b_hi = b_lo + P.seg_blocks < nblk ? b_lo + P.seg_blocks : nblk;
@@ -169,32 +188,37 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
         } else {
             // sum the long-block inputs and the short-block inputs of this output
             // separately (the transforms are linear), at most one transform of each kind
+            uint32_t swm = 0;                       // bit c: input plane c is a short block here
+            if (swbase) {
+                const uint8_t *q = swbase + (size_t)b * P.nfchans;
+#pragma unroll
+                for (int fb = 0; fb < 5; fb++)
+                    if (fb < P.nfchans) swm |= (q[fb] ? 1u : 0u) << (fb + P.in_lfe);
+            }
             float xa[16], xb[16];
             bool any;
 #pragma unroll
             for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
             any = false;
-            for (int c = 0; c < P.n_in; c++) {
-                const int m = P.mix[o][c];
-                if (!m) continue;
-                const int fb = c - P.in_lfe;
-                const int sw = (swbase && fb >= 0) ? swbase[(size_t)b * P.nfchans + fb] : 0;
-                if (sw) continue;
-                load_long(cblk + (size_t)c * 256, l8, (float)m, xa, xb);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (k >= pcnt) continue;
+                const int c = (plist >> (3 * k)) & 7;
+                if ((swm >> c) & 1) continue;
+                load_long(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
                 any = true;
             }
             if (any) imdct_long(xa, xb, twl, ex, l8, ft);
-            if (swbase) {
+            if (swm) {
 #pragma unroll
                 for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
                 any = false;
-                for (int c = 0; c < P.n_in; c++) {
-                    const int m = P.mix[o][c];
-                    if (!m) continue;
-                    const int fb = c - P.in_lfe;
-                    const int sw = (fb >= 0) ? swbase[(size_t)b * P.nfchans + fb] : 0;
-                    if (!sw) continue;
-                    load_short(cblk + (size_t)c * 256, l8, (float)m, xa, xb);
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    if (k >= pcnt) continue;
+                    const int c = (plist >> (3 * k)) & 7;
+                    if (!((swm >> c) & 1)) continue;
+                    load_short(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
                     any = true;
                 }
                 if (any) {
@@ -313,7 +337,7 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     }
     if (identity)
         hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, P);
-    else
+    else        // 187 VGPRs: 2 workgroups per CU; forced to 3 it spills and runs 1.26 ms instead of 0.81 (65 536 frames, 5.1 -> 2.0)
         hipLaunchKernelGGL((xform_kernel<true, 2>), dim3(grid), dim3(256), 0, stream, P);
     return hipGetLastError();
 }

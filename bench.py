@@ -215,8 +215,20 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     def do_transcode():
         eng.transcode_batch(dec, enc, frames, delay2, lfsr2, chmap, last2, csnr2, out=frames2, status=status, wait_torch=False)
 
+    # BASELINE configs[3]: mixed short/long blocks (a quarter of the channel-blocks switched) with the 5.1 -> 2.0
+    # downmix folded into the transform: 5 of the 6 planes in (liba52 drops the LFE), 2 planes out, 2 overlap tails
+    mixdesc = pkg.XformDesc(7, 1, 2, 0.0)
+    coef_mix = torch.randn((S, 1, 6, 6, 256), device=dev, generator=g) * 0.05
+    blksw_mix = (torch.rand((S, 1, 6, 5), device=dev, generator=g) < 0.25).to(torch.uint8)
+    delay_mix = torch.zeros((S, 2, 128), dtype=torch.float32, device=dev)
+    out_mix = torch.empty((S, 1, 6, 2, 256), dtype=torch.float32, device=dev)
+
+    def do_mix():
+        eng.imdct_batch(mixdesc, coef_mix, delay_mix, blksw=blksw_mix, out=out_mix, wait_torch=False)
+
     res = {}
-    for name, fn, nbytes in (("encode", do_enc, 18432 + 1536 + 2 * 3072),
+    for name, fn, nbytes in (("transform_downmix_mixed_blocks", do_mix, 30720 + 12288 + 2 * 1024),   # the LFE plane is not mixed in
+                             ("encode", do_enc, 18432 + 1536 + 2 * 3072),
                              ("decode", do_dec, 1536 + 36864 + 2 * 3072),
                              ("decode_s16", do_dec16, 1536 + 18432 + 2 * 3072),
                              ("transcode", do_transcode, 38400 + 19968)):
