@@ -430,7 +430,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(S),
-                "kernel": "ac3mi::xform_kernel<false, 4>",
+                "kernel": "ac3mi::xform_kernel<false, 4, false>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
             },
