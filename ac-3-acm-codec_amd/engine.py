@@ -247,6 +247,9 @@ class Engine:
         dev = pcm.device
         if out is None:
             out = torch.zeros((S, F, stride), dtype=torch.uint8, device=dev)
+        else:
+            assert out.dtype == torch.uint8 and out.is_contiguous() and out.shape[:2] == (S, F) and out.shape[2] >= stride and out.shape[2] % 4 == 0
+            stride = out.shape[2]
         cm = (ctypes.c_uint8 * 8)(*(list(chmap) + [0] * 8)[:8])
         tp, tdict = None, None
         if taps:

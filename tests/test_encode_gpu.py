@@ -176,6 +176,34 @@ def test_encode_extreme_levels(engine, kind, nch, bitrate):
     assert H.rms(dec.astype(np.float64) - ref_pcm) <= 1e-6
 
 
+def test_starved_bit_rate_is_survivable(engine):
+    """6 channels of noise at 64 kbps: AC3_encode_init accepts it, but not even csnroffst 0 fits the frame, the
+    reference prints "Yack, Error !!!" (ac3enc.cpp:930-933), keeps going with stale offsets and writes past the frame
+    size; the oracle gives up (-1).  There is nothing to be bit-exact with.  The engine must stay inside its buffers,
+    produce a frame-sized output with a header, leave neighbours alone and keep working: a stream with the same
+    samples at 384 kbps, encoded right after with the same context, is still byte-exact."""
+    import torch
+    pkg = H.pkg()
+    S, F = 3, 2
+    pcm = [H.gen_pcm(F, 6, seed=880 + s, kind="noise") for s in range(S)]
+    desc = pkg.EncodeDesc(48000, 64000, 6)
+    fb = desc.frame_bytes()
+    assert fb == 256
+    t = torch.from_numpy(np.stack(pcm).reshape(S, F, 1536, 6)).cuda()
+    last = torch.zeros((S, 6, 256), dtype=torch.int16, device="cuda")
+    csnr = torch.full((S,), 40, dtype=torch.int32, device="cuda")
+    guard = torch.full((S, F, fb + 64), 0xA5, dtype=torch.uint8, device="cuda")       # 64 guard bytes behind every frame
+    out = engine.encode_batch(desc, t, H.CHMAP6, last, csnr, out=guard)
+    engine.sync()
+    o = out.cpu().numpy()
+    assert (o[:, :, 0] == 0x0b).all() and (o[:, :, 1] == 0x77).all()
+    assert (o[:, :, fb:] == 0xA5).all(), "wrote past the frame"
+    assert (csnr.cpu().numpy() == 40).all()          # a failed search leaves the stream's start value alone (:921-933)
+    want, _ = _oracle(pcm, 6, 384000)
+    got, _ = _gpu(engine, pcm, 6, 384000, taps=False)
+    assert np.array_equal(got, want)
+
+
 def test_batch_shape_paths_agree(engine):
     """One call with six frames per stream goes through the tabulate / replay / pack-per-frame kernels; six calls of one
     frame each go through the one-wavefront-per-stream kernel with the state carried by the caller.  Same bytes."""
