@@ -320,6 +320,32 @@ using namespace ac3mi;
         }                                                                              \
     } while (0)
 
+// Measurement aid: what one SIMD sustains in plain 32-bit VALU instructions while the whole chip is busy with them
+// (the issue ceiling the instruction-bound kernels are priced against; the clock under such a load is not the
+// data-sheet peak).  Every wavefront executes iters x 32 v_add_u32 / v_xor_b32 on eight independent registers.
+namespace ac3mi {
+__global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t *out, int iters)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t k = blockIdx.x | 1u;
+    for (int i = 0; i < iters; i++) {
+        asm volatile(
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(k));
+    }
+    const uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345678u) out[0] = r;               // keeps the chain alive; practically never taken
+}
+}  // namespace ac3mi
+
 extern "C" {
 
 int ac3mi_device_count(void)
@@ -497,6 +523,28 @@ int ac3mi_timer_stop(ac3mi_ctx *ctx, float *elapsed_ms)
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return AC3MI_OK;
+}
+
+int ac3mi_probe_valu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd)
+{
+    if (!ctx || !ginst_per_s_per_simd) return AC3MI_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount, wg_per_cu = 8, iters = 8192;        // 8 wavefronts per SIMD
+    uint32_t *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, 64));
+    hipLaunchKernelGGL(valu_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, 64);       // warm-up
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(valu_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, iters);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    (void)hipFree(d);
+    // per SIMD: wg_per_cu workgroups x 4 wavefronts / 4 SIMDs = wg_per_cu wavefronts, 32 instructions per iteration each
+    *ginst_per_s_per_simd = (double)wg_per_cu * iters * 32.0 / (ms * 1e-3) / 1e9;
     return AC3MI_OK;
 }
 

@@ -200,6 +200,12 @@ class Engine:
         self._keep.append((frames, delay, lfsr, out, status))
         return out, status
 
+    def probe_valu_rate(self):
+        """10^9 VALU instructions/s one SIMD sustains under a chip-wide VALU load (ac3mi_probe_valu_rate)."""
+        v = ctypes.c_double()
+        self._check(self.lib.ac3mi_probe_valu_rate(ctypes.c_void_p(self.ctx), ctypes.byref(v)))
+        return v.value
+
     def set_tile_frames(self, frames):
         """Workspace bound: batches above `frames` frames go through in tiles of whole streams (ac3mi_set_tile_frames)."""
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))

@@ -251,6 +251,11 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     ok = int((status & 0x1ff).max().item()) == 0
     res["decode"]["all_frames_ok"] = ok
     res["_frames"] = frames[:64].cpu().numpy()          # for the CPU rates beside these legs (dropped from the line)
+    # the issue ceiling of the instruction-bound kernels: plain VALU instructions per second and SIMD, chip-wide load
+    rate = eng.probe_valu_rate()
+    res["valu_probe"] = {"ginst_per_s_per_simd": rate,
+                         "note": "plain 32-bit VALU instructions one SIMD sustains with all SIMDs busy (8 wavefronts each); "
+                                 "decode / encode kernels are priced against this in DESIGN.md"}
     if os.environ.get("AC3MI_BENCH_MILLION") == "1":
         res["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, frames)
     if dist is None:           # host-side work on up to 16 threads: single-process runs only

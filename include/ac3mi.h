@@ -73,6 +73,11 @@ int ac3mi_sync(ac3mi_ctx *ctx);
 int ac3mi_timer_start(ac3mi_ctx *ctx);
 int ac3mi_timer_stop(ac3mi_ctx *ctx, float *elapsed_ms);   /* synchronises */
 
+/* Measurement aid: 10^9 plain 32-bit VALU instructions per second one SIMD sustains with every SIMD of the device busy
+ * doing the same (a gfx950 SIMD issues a wave64 VALU instruction in 2 cycles).  DESIGN.md prices the decode / encode
+ * kernels against it. */
+int ac3mi_probe_valu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd);
+
 /* ---- block transform: IMDCT-512/256 + KBD window + overlap-add + downmix ---- */
 
 /* Replaces the synthesis stage of a52_block (L52/parse.c:881-937): a52_imdct_512

@@ -11,7 +11,7 @@ import csv, glob, collections
 for fn in glob.glob("$OUT/a/*counter_collection.csv"):
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fn)):
-        k=r["Kernel_Name"][:40]
+        k=r["Kernel_Name"][:52]
         if "ac3mi" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,d in acc.items():
         w=sum(d["SQ_WAVES"])/len(d["SQ_WAVES"])
