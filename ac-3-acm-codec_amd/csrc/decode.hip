@@ -26,6 +26,11 @@
 namespace ac3mi {
 
 constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dwords, conflict-free across rows
+// The LFE row holds 7 exponents (bit_allocate_wave's lowcomp stage looks at bins up to 64 of any row): kept short and
+// last, which brings the wavefront's LDS under 8 KB = 20 wavefronts per CU, what the 96 VGPRs allow.
+constexpr int LFE_ROW = 68;
+constexpr int ROWS = 6 * ROW + LFE_ROW;
+__device__ __forceinline__ int row_off(int slot) { return slot < 5 ? slot * ROW : slot == 6 ? 5 * ROW : 6 * ROW; }
 
 __device__ const uint8_t k_nfchans[11] = {2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2};
 __device__ const float k_clev[4] = {(float)AC3MI_G_3DB, (float)AC3MI_G_45DB, (float)AC3MI_G_6DB, (float)AC3MI_G_45DB};
@@ -39,8 +44,8 @@ __device__ const uint16_t k_kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 16
 
 // channel slots: 0..4 = fbw, 5 = lfe, 6 = coupling channel
 struct DecLDS {
-    uint8_t exp[7][ROW];
-    int8_t bap[7][ROW];
+    uint8_t exp[ROWS];                    // rows at row_off(slot)
+    int8_t bap[ROWS];
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
     uint8_t gcode[128];                   // open 3/5/11-level codes: rings of 32 / 32 / 64 (a step opens <= 22 / 22 / 32)
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
     for (int i = lane; i < 760; i += 64) L.qtab[i] = (int16_t)P.tab->qtab[i];
     for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
-    for (int i = lane; i < 7 * ROW; i += 64) { (&L.exp[0][0])[i] = 0; (&L.bap[0][0])[i] = 0; }
+    for (int i = lane; i < ROWS; i += 64) { L.exp[i] = 0; L.bap[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
     for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
 
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                     const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
                     const int e0 = rd.get(4) << 1;
                     redo = 64;
-                    if (read_exponents(FB, rd.pos, cplexpstr, ngrp, e0, &L.exp[6][st.cplstrtmant], lane)) { err = 1; break; }
+                    if (read_exponents(FB, rd.pos, cplexpstr, ngrp, e0, L.exp + row_off(6) + st.cplstrtmant, lane)) { err = 1; break; }
                     rd.pos += 7 * ngrp;
                 }
 #pragma unroll
@@ -609,8 +614,8 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                         const int gs = 3 << (es - 1), ngrp = (st.endmant[i] + gs - 4) / gs;
                         redo |= 1 << i;
                         const int e0 = rd.get(4);
-                        if (lane == 0) L.exp[i][0] = (uint8_t)e0;
-                        if (read_exponents(FB, rd.pos, es, ngrp, e0, &L.exp[i][1], lane)) err = 1;
+                        if (lane == 0) L.exp[row_off(i)] = (uint8_t)e0;
+                        if (read_exponents(FB, rd.pos, es, ngrp, e0, L.exp + row_off(i) + 1, lane)) err = 1;
                         rd.pos += 7 * ngrp;
                         rd.get(2);                                          // gainrng
                     }
@@ -619,8 +624,8 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                 if (lfeexpstr) {
                     redo |= 32;
                     const int e0 = rd.get(4);
-                    if (lane == 0) L.exp[5][0] = (uint8_t)e0;
-                    if (read_exponents(FB, rd.pos, lfeexpstr, 2, e0, &L.exp[5][1], lane)) { err = 1; break; }
+                    if (lane == 0) L.exp[row_off(5)] = (uint8_t)e0;
+                    if (read_exponents(FB, rd.pos, lfeexpstr, 2, e0, L.exp + row_off(5) + 1, lane)) { err = 1; break; }
                     rd.pos += 14;
                 }
 
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                     for (int i = 0; i < 5; i++)
                         if (i < nf && (st.cbai[i] >> 3)) allzero = false;
                     if (allzero) {
-                        for (int i = lane; i < 7 * ROW; i += 64) (&L.bap[0][0])[i] = 0;
+                        for (int i = lane; i < ROWS; i += 64) L.bap[i] = 0;
                     } else {
                         // channel slots in turn (wave-uniform), each allocated by the whole wavefront
                         for (int slot = 0; slot < 7; slot++) {
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                             c.floor = fl >> 5;
                             c.fast = fl0;
                             c.slow = sl0;
-                            bit_allocate_wave(L, c, bndstart, start, end, L.exp[slot], L.bap[slot], lane);
+                            bit_allocate_wave(L, c, bndstart, start, end, L.exp + row_off(slot), L.bap + row_off(slot), lane);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -738,7 +743,11 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                 uint8_t *te = P.tap_exp + (fidx * 6 + blk) * 7 * 256;
                 int8_t *tb = P.tap_bap + (fidx * 6 + blk) * 7 * 256;
                 for (int c = 0; c < 7; c++)
-                    for (int i = lane; i < 256; i += 64) { te[c * 256 + i] = L.exp[c][i]; tb[c * 256 + i] = L.bap[c][i]; }
+                    for (int i = lane; i < 256; i += 64) {
+                        const bool in = c != 5 || i < LFE_ROW;
+                        te[c * 256 + i] = in ? L.exp[row_off(c) + i] : 0;
+                        tb[c * 256 + i] = in ? L.bap[row_off(c) + i] : 0;
+                    }
             }
 
             if (!err) {
@@ -805,8 +814,8 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                     for (int i0 = 0; i0 < len; i0 += 64) {
                         const bool act = i0 + lane < len;
                         const int bin = start + (act ? i0 + lane : 0);
-                        const int w = act ? (int)L.bap[ch][bin] : -9;
-                        const int e = L.exp[ch][bin];
+                        const int w = act ? (int)L.bap[row_off(ch) + bin] : -9;
+                        const int e = L.exp[row_off(ch) + bin];
                         const int kind = w == -1 ? 0 : w == -2 ? 1 : w == -3 ? 2 : -1;
                         const uint32_t gcnt = kind < 0 ? 0u : 1u << (8 * kind);
                         const uint32_t gincl = wave_incl_scan_u32(gcnt);
@@ -973,7 +982,8 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
     P.frame_draws = L.frame_draws;
     P.frame_lfsr = L.frame_lfsr;
-    const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 4) * 4;
+    static const int lds_pad = getenv("AC3MI_DEC_LDS_PAD") ? atoi(getenv("AC3MI_DEC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
+    const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 4) * 4 + lds_pad;
     if (!L.frame_parallel) {
         hipLaunchKernelGGL(decode_kernel<0>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
         return hipGetLastError();
