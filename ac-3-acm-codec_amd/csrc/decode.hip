@@ -16,7 +16,7 @@
 //  * mantissas: one sweep, 64 consecutive coefficients of a channel segment per step; two packed
 //    DPP scans give grouped-code ranks, bit offsets and dither draw indices (the LFSR is
 //    GF(2)-linear, so the k-th draw is a table lookup: lfsr_seq[(lfsr_idx[state] + k) mod 65535]);
-//    dequantisation through one LDS table; planes go straight to HBM
+//    dequantisation through one table (L1-resident); planes go straight to HBM
 //
 // Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
 #include "ac3mi_internal.h"
@@ -27,7 +27,8 @@ namespace ac3mi {
 
 constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dwords, conflict-free across rows
 // The LFE row holds 7 exponents (bit_allocate_wave's lowcomp stage looks at bins up to 64 of any row): kept short and
-// last, which brings the wavefront's LDS under 8 KB = 20 wavefronts per CU, what the 96 VGPRs allow.
+// last; with the dequantiser table read through L1 the wavefront's LDS is 6.5 KB = 24 wavefronts per CU, what the
+// 80 VGPRs of __launch_bounds__(64, 6) allow (the kernel is latency-bound, occupancy pays).
 constexpr int LFE_ROW = 68;
 constexpr int ROWS = 6 * ROW + LFE_ROW;
 __device__ __forceinline__ int row_off(int slot) { return slot < 5 ? slot * ROW : slot == 6 ? 5 * ROW : 6 * ROW; }
@@ -49,7 +50,6 @@ struct DecLDS {
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
     uint8_t gcode[128];                   // open 3/5/11-level codes: rings of 32 / 32 / 64 (a step opens <= 22 / 22 / 32)
-    int16_t qtab[760];                    // dequantised code members (DecTables::qtab; integers below 2^15)
     uint8_t cplbnd[20];                   // coupling sub-band -> band
     int16_t seg_base[9];                  // mantissa stream segments
     uint8_t seg_ch[8], seg_start[8];
@@ -387,7 +387,7 @@ __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t 
 // wavefront per frame, everything but the mantissa values) finds each frame's number of dither draws, a prefix pass
 // turns them into the LFSR state every frame starts from, and MODE 2 decodes all frames at once.
 template <int MODE>
-__global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
+__global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
 {
     __shared__ DecLDS L;
     extern __shared__ uint32_t frw[];
@@ -403,7 +403,6 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
     if (lane < 50) L.hth[lane] = 0;
     L.width[lane] = P.tab->width[lane];
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
-    for (int i = lane; i < 760; i += 64) L.qtab[i] = (int16_t)P.tab->qtab[i];
     for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
     for (int i = lane; i < ROWS; i += 64) { L.exp[i] = 0; L.bap[i] = 0; }
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
@@ -857,7 +856,7 @@ __global__ __launch_bounds__(64, 5) void decode_kernel(const DecodeParams P)
                             const int code = kind >= 0 ? (int)L.gcode[gslot] : (int)raw;
                             const int base = kind == 0 ? 0 : kind == 1 ? 96 : kind == 2 ? 480 : w == 3 ? 736 : 744;
                             const int ti = base + code * (kind >= 0 ? per : 1) + (kind >= 0 ? mem : 0);
-                            const float tv = (float)L.qtab[coded ? ti : 0];
+                            const float tv = (float)P.tab->qtab[coded ? ti : 0];
                             const float pv = (float)((((int32_t)(raw << ((32 - w) & 31))) >> ((32 - w) & 31)) * (1 << ((16 - w) & 31)));
                             q = coded ? tv : w > 0 ? pv : 0.f;
                         }

@@ -65,10 +65,9 @@ struct PackParams {
     uint32_t crc_inv;           // x^-(16*fs58-16) mod poly (:1627)
     uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
     int c1, c2;                 // CRC chunk bytes per lane
+    int frw;                    // dwords of the frame buffer in (dynamic) LDS: the frame + 256 bytes of headroom, multiple of 4
 };
 
-constexpr int PK_MAXBYTES = 3840 + 256;
-constexpr int PK_FRW = PK_MAXBYTES / 4;
 
 
 // tables of the PSD / masking-curve computation
@@ -83,7 +82,7 @@ struct alignas(16) PackLDS {
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
     uint32_t gtab[128];         // 3/5/11-level codes being assembled, rings of 32 / 32 / 64: bit offset | 16-bit code << 16
     uint32_t bitlut[64];        // see lut_index
-    uint32_t fr[PK_FRW];        // frame as MSB-first dwords (+256 bytes headroom for the overshoot quirk)
+    // (the frame itself, MSB-first dwords + 256 bytes of headroom for the overshoot quirk, is dynamic LDS: PackParams::frw)
     int8_t shiftv[36];          // exp_samples of the frame
     uint8_t strat[6][6];
     uint8_t band_of_bin[256];
@@ -92,11 +91,11 @@ struct alignas(16) PackLDS {
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
 // the bits before the field as far as the 32-bit word it starts in, which is what the 64-bit shift below does.
-__device__ __forceinline__ void put_bits(uint32_t *fr, uint32_t pos, int n, uint32_t v)
+__device__ __forceinline__ void put_bits(uint32_t *fr, int frw, uint32_t pos, int n, uint32_t v)
 {
     if (n <= 0) return;
     const uint32_t w = pos >> 5;
-    if (w + 1 >= (uint32_t)PK_FRW) return;
+    if (w + 1 >= (uint32_t)frw) return;
     const uint64_t x = (uint64_t)v << (64 - n - (pos & 31));
     const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
     if (hi) atomicOr(&fr[w], hi);
@@ -769,14 +768,14 @@ __device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :116
 
 // CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
 // bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
-__device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
+__device__ uint32_t region_crc(const PackLDS &L, const uint32_t *fr, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
 {
     const int start = end - 64 * C;                 // may be negative: leading zero padding
     int p = start + lane * C;
     uint32_t crc = 0;
     for (int i = 0; i < C; i++, p++) {
         uint32_t byte = 0;
-        if (p >= end - len && p >= zero_below) byte = (L.fr[p >> 2] >> (24 - 8 * (p & 3))) & 0xff;
+        if (p >= end - len && p >= zero_below) byte = (fr[p >> 2] >> (24 - 8 * (p & 3))) & 0xff;
         crc = (L.crc_tab[byte ^ (crc >> 8)] ^ (crc << 8)) & 0xffff;
     }
 #pragma unroll
@@ -795,9 +794,11 @@ __device__ uint32_t region_crc(const PackLDS &L, int end, int len, int C, const 
 // from those tables - costing an offset itself only when the table has no answer - and leaves csnroffst / fsnroffst
 // of every frame in P.snr; PART 2 (one wavefront per frame) packs all frames at once.
 template <int PART>
-__global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
+    extern __shared__ uint4 pk_dyn[];
+    uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
     const int lane = threadIdx.x;
     constexpr bool PER_FRAME = PART == 2 || PART == 3;
     const int s = PER_FRAME ? (int)(blockIdx.x / (unsigned)P.frames_per_stream) : (int)blockIdx.x;
@@ -853,8 +854,8 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                 if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             }
             frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
-            if (PART != 1)
-                for (int i = lane; i < PK_FRW / 4; i += 64) reinterpret_cast<uint4 *>(L.fr)[i] = make_uint4(0, 0, 0, 0);
+            if (PART == 0 || PART == 2)
+                for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
             WAVE_SYNC();
 
             // ---- fixed side information (:880-916) ----
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         // ---- header (:1113-1147) ----
         uint32_t pos = 0;
         auto put = [&](int n, uint32_t v) {
-            if (lane == 0) put_bits(L.fr, pos, n, v);
+            if (lane == 0) put_bits(fr, P.frw, pos, n, v);
             pos += n;
         };
         put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
@@ -1090,7 +1091,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                     const int k0 = 1 + 3 * g * gs;
                     const int prev = g ? e[k0 - gs] : e[0];
                     const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
-                    put_bits(L.fr, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+                    put_bits(fr, P.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
                 }
                 pos += 7 * ng;
                 if (!is_lfe) put(2, 0);
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                     const bool sym = grouped || bp == 3 || bp == 5;
                     const int v = sym ? quant_sym(c, e, levels) : quant_asym(c, e, w ? w : 1);
                     // quantised values live in 16 bits (qmant[] is unsigned short, :1347); only out-of-contract ones are wider than their field
-                    if (!grouped) put_bits(L.fr, off, w, (uint32_t)v & 0xffffu);
+                    if (!grouped) put_bits(fr, P.frw, off, w, (uint32_t)v & 0xffffu);
 
                     // a step opens at most 22 / 22 / 32 groups and one older group per kind can be incomplete
                     uint32_t *slot = kind == 2 ? &L.gtab[64 + (grp & 63)] : &L.gtab[(kind == 1 ? 32 : 0) + (grp & 31)];
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                     WAVE_SYNC();
                     if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt) << 16);
                     WAVE_SYNC();
-                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(L.fr, x & 0xffffu, gbits, x >> 16); }
+                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16); }
 
                     b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
                     pos += wave_last(bincl);
@@ -1194,9 +1195,9 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
                 // a trailing group that never got its last member is written as it stands
                 WAVE_SYNC();
                 if (lane == 0) {
-                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(L.fr, x & 0xffffu, 5, x >> 16); }
-                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(L.fr, x & 0xffffu, 7, x >> 16); }
-                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(L.fr, x & 0xffffu, 7, x >> 16); }
+                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(fr, P.frw, x & 0xffffu, 5, x >> 16); }
+                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(fr, P.frw, x & 0xffffu, 7, x >> 16); }
+                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(fr, P.frw, x & 0xffffu, 7, x >> 16); }
                 }
             }
             WAVE_SYNC();
@@ -1206,20 +1207,20 @@ __global__ __launch_bounds__(64, 4) void enc_pack_kernel(const PackParams P)
         const int fs58 = (fs >> 1) + (fs >> 3);
         // clear everything from byte 2*fs-2 on? no: the reference only zero-pads when the data is short;
         // data bits beyond byte 2*fs-2 stay and are then overwritten by crc2 (its own overshoot quirk)
-        uint32_t crc1 = region_crc(L, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
+        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
         crc1 = gf_mul(P.crc_inv, crc1);
-        const uint32_t crc2 = region_crc(L, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
+        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
         WAVE_SYNC();
         if (lane == 0) {
-            L.fr[0] = (L.fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
+            fr[0] = (fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
             const int p = 2 * fs - 2;                                                 // even -> inside one dword
             const int shft = 16 - 8 * (p & 3);
-            L.fr[p >> 2] = (L.fr[p >> 2] & ~(0xffffu << shft)) | ((crc2 & 0xffff) << shft);
+            fr[p >> 2] = (fr[p >> 2] & ~(0xffffu << shft)) | ((crc2 & 0xffff) << shft);
         }
         WAVE_SYNC();
         uint8_t *dst = P.frames + fidx * P.frame_stride;
         for (int i = lane; i < (2 * fs + 3) / 4; i += 64) {
-            uint32_t v = __builtin_bswap32(L.fr[i]);
+            uint32_t v = __builtin_bswap32(fr[i]);
             const int rem = 2 * fs - 4 * i;
             if (rem >= 4) *reinterpret_cast<uint32_t *>(dst + 4 * i) = v;
             else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
@@ -1324,14 +1325,17 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     }
     P.snr = E.ws_snr;
     P.memo = nullptr;
+    P.frw = ((2 * fs + 256 + 15) / 16) * 4;
+    static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
+    const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
     if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {
         // few long streams: searches per stream, then all frames packed at once
         P.memo = E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
-        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
-        hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
-        hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 0, stream, P);
+        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 16, stream, P);
+        hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 16, stream, P);
+        hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), fr_lds, stream, P);
     } else {
-        hipLaunchKernelGGL(enc_pack_kernel<0>, dim3(E.n_streams), dim3(64), 0, stream, P);
+        hipLaunchKernelGGL(enc_pack_kernel<0>, dim3(E.n_streams), dim3(64), fr_lds, stream, P);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
