@@ -749,9 +749,9 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
 
     const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
-    // A large batch goes through in four chunks of streams: the (HBM-bound) transform of chunk i runs on a
+    // A large batch goes through in two chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 4 : 1;       // measured: 4.79 -> 4.66 ms on 65536 frames
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 5.06 / 4.93 / 4.94 / 5.04 ms (4 was best before the front end ran 6 waves/SIMD)
     const size_t F = (size_t)frames_per_stream;
     for (int k = 0; k < n_chunks; k++) {
         const int s0 = (int)((long long)n_streams * k / n_chunks), s1 = (int)((long long)n_streams * (k + 1) / n_chunks);

@@ -527,12 +527,12 @@ __device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int
     q.im = (int16_t)((by - ay) >> 1);
 }
 
-__global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
+__global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
 {
     __shared__ int16_t in[512];
     __shared__ c16 z[128];
     __shared__ int32_t out[256];
-    __shared__ int16_t win[256], xc[128], xs[128], ct[64], sn[64];
+    __shared__ int16_t xc[128], xs[128], ct[64], sn[64];
     __shared__ uint8_t rev[128];
     __shared__ ExpLDS XL;
 
@@ -543,7 +543,10 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
     const int f = sf % P.frames;
     const int s = sf / P.frames;
 
-    for (int i = lane; i < 256; i += 64) win[i] = P.tab->win[i];
+    // the window values this lane ever needs (samples lane + 64k of either half): registers, not LDS
+    int wa[4], wb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { wa[k] = P.tab->win[lane + 64 * k]; wb[k] = P.tab->win[255 - lane - 64 * k]; }
     for (int i = lane; i < 128; i += 64) { xc[i] = P.tab->xcos[i]; xs[i] = P.tab->xsin[i]; rev[i] = P.tab->bitrev[i]; }
     ct[lane] = P.tab->cos[lane];
     sn[lane] = P.tab->sin[lane];
@@ -576,8 +579,8 @@ __global__ __launch_bounds__(64) void enc_mdct_kernel(const MdctParams P)
                 else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
             }
             // window (:1686-1693)
-            in[j] = (int16_t)((oldv[k] * win[j]) >> 15);
-            in[256 + j] = (int16_t)((newv[k] * win[255 - j]) >> 15);
+            in[j] = (int16_t)((oldv[k] * wa[k]) >> 15);
+            in[256 + j] = (int16_t)((newv[k] * wb[k]) >> 15);
             oldv[k] = newv[k];
         }
         WAVE_SYNC();

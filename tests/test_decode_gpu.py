@@ -194,7 +194,7 @@ def test_damaged_frames_match_liba52_block_by_block(engine, acmod, lfe, seed):
 
 
 def test_large_batch_goes_through_the_chunk_pipeline(engine):
-    """>= 16384 frames: ac3mi_decode_batch splits the streams into four chunks and runs each chunk's transform on a
+    """>= 16384 frames: ac3mi_decode_batch splits the streams into chunks and runs each chunk's transform on a
     second HIP stream.  Replicated streams must decode to identical PCM, taps and state whatever chunk they fall in."""
     import torch
     pkg = H.pkg()
