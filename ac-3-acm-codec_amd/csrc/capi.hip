@@ -1021,7 +1021,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames: 13.0 (1), 12.7 (2), 12.75 ms (4)
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
