@@ -909,6 +909,11 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                     if (c >= nf) continue;
                     const int from = ((st.chincpl >> c) & 1) ? st.cplendmant : st.endmant[c];
                     for (int i = from + lane; i < 256; i += 64) cblk[(c + in_lfe) * 256 + i] = 0.f;
+                    // a damaged frame can move the coupling region away from a channel that reuses its exponents:
+                    // liba52 then leaves the previous block's PCM in [endmant, cplstrtmant) (its buffer is transformed
+                    // in place); here those bins are zero
+                    if (((st.chincpl >> c) & 1) && st.endmant[c] < st.cplstrtmant)
+                        for (int i = st.endmant[c] + lane; i < st.cplstrtmant; i += 64) cblk[(c + in_lfe) * 256 + i] = 0.f;
                 }
                 if (st.lfeon) for (int i = 7 + lane; i < 256; i += 64) cblk[i] = 0.f;
             }

@@ -288,6 +288,18 @@ void orc_a52_get_coefs(orc_a52_t *st, float *dst6x256, uint8_t *blksw5)
 int orc_a52_get_lfsr(orc_a52_t *st) { return st->lfsr; }
 void orc_a52_set_lfsr(orc_a52_t *st, int v) { st->lfsr = (uint16_t)v; }
 int orc_a52_get_output(orc_a52_t *st) { return st->output; }
+/* endmant[0..4], cplstrtmant, cplendmant, chincpl of the block just parsed: lets a test find the bins liba52 never
+ * writes when a damaged frame moves the coupling region away from a channel that reuses its exponents
+ * (parse.c:813-835 fills [0, endmant), the coupling range and [cplendmant, 256): a gap between endmant and
+ * cplstrtmant keeps the previous block's PCM, the buffer being transformed in place). */
+void orc_a52_get_layout(orc_a52_t *st, int *out8)
+{
+    int i;
+    for (i = 0; i < 5; i++) out8[i] = st->endmant[i];
+    out8[5] = st->cplstrtmant;
+    out8[6] = st->cplendmant;
+    out8[7] = st->chincpl;
+}
 
 /* ------------------------------------------------------------------ */
 /* sync + BSI: liba52/parse.c:86-205                                   */

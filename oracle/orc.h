@@ -44,6 +44,7 @@ void orc_a52_get_coefs(orc_a52_t *st, float *dst6x256, uint8_t *blksw5);
 int orc_a52_get_lfsr(orc_a52_t *st);
 void orc_a52_set_lfsr(orc_a52_t *st, int v);
 int orc_a52_get_output(orc_a52_t *st);
+void orc_a52_get_layout(orc_a52_t *st, int *out8);
 long orc_a52_bitpos(orc_a52_t *st);
 
 /* transform-only entry points (liba52/a52_internal.h:106-120) */

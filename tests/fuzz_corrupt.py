@@ -40,6 +40,10 @@ def make_damaged(seed, acmod, lfe, S=96, fscod=0, bsid=8, frmsizecod=30, base_st
     want_fail = np.full(S, 6)                            # first failing block (6 = none)
     want_foreign = np.zeros(S, bool)
     want_lfsr = np.zeros(S, np.int64)
+    gap = np.zeros((S, 6, 6, 256), bool)                 # bins liba52 leaves untouched (see orc_a52_get_layout): engine = 0
+    lay = (ctypes.c_int * 8)()
+    L.orc_a52_get_layout.argtypes = [H.vp, ctypes.POINTER(ctypes.c_int)]
+    L.orc_a52_get_layout.restype = None
     sw = np.zeros(5, np.uint8)
     for s in range(S):
         st = L.orc_a52_init()
@@ -55,8 +59,13 @@ def make_damaged(seed, acmod, lfe, S=96, fscod=0, bsid=8, frmsizecod=30, base_st
                     want_fail[s] = b
                     break
                 L.orc_a52_get_coefs(st, H.P(want_coef[s, b], H.fp), H.P(sw, H.u8p))
+                L.orc_a52_get_layout(st, lay)
+                for c in range(H.NFCHANS[acmod]):
+                    if (lay[7] >> c) & 1 and lay[c] < lay[5]:
+                        gap[s, b, c + lfe, lay[c]:lay[5]] = True
         want_lfsr[s] = L.orc_a52_get_lfsr(st)
         L.orc_a52_free(st)
+    want_coef[gap] = 0.0
     return frames, want_coef, want_fail, want_foreign, want_lfsr
 
 
