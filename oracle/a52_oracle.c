@@ -292,6 +292,16 @@ int orc_a52_get_output(orc_a52_t *st) { return st->output; }
  * writes when a damaged frame moves the coupling region away from a channel that reuses its exponents
  * (parse.c:813-835 fills [0, endmant), the coupling range and [cplendmant, 256): a gap between endmant and
  * cplstrtmant keeps the previous block's PCM, the buffer being transformed in place). */
+/* deltbae of the five fbw channels and of the coupling channel after the block just parsed.  liba52's a52_init does not
+ * clear its state (malloc, parse.c:59): a damaged frame that says "reuse" (0) or the reserved 3 before any "new" (1)
+ * makes it allocate bits from uninitialised deltba[] arrays (bit_allocate.c:  deltba = deltbae == NONE ? NULL : ...);
+ * this restatement starts from zeros.  Tests use the getter to leave such frames out. */
+void orc_a52_get_deltbae(orc_a52_t *st, int *out6)
+{
+    int i;
+    for (i = 0; i < 5; i++) out6[i] = st->ba[i].deltbae;
+    out6[5] = st->cplba.deltbae;
+}
 void orc_a52_get_layout(orc_a52_t *st, int *out8)
 {
     int i;

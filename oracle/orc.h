@@ -45,6 +45,7 @@ int orc_a52_get_lfsr(orc_a52_t *st);
 void orc_a52_set_lfsr(orc_a52_t *st, int v);
 int orc_a52_get_output(orc_a52_t *st);
 void orc_a52_get_layout(orc_a52_t *st, int *out8);
+void orc_a52_get_deltbae(orc_a52_t *st, int *out6);
 long orc_a52_bitpos(orc_a52_t *st);
 
 /* transform-only entry points (liba52/a52_internal.h:106-120) */
