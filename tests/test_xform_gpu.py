@@ -69,11 +69,16 @@ def test_bias_and_streaming_state(engine):
     r1, st = H.orc_xform(c1, None, 7, 1, 7 | 16, bias=384.0)
     r2, st = H.orc_xform(c2, None, 7, 1, 7 | 16, bias=384.0, state=st)
     delay = torch.zeros((S, 6, 128), dtype=torch.float32, device="cuda")
+    # a third call: the second one ran as whole-frame segments (few chains, two frames), and the tails it left behind
+    # were written by segment 0's extra pass over the chain's last block
+    c3 = _coefs(rng, S, 3, 6)
+    r3, st = H.orc_xform(c3, None, 7, 1, 7 | 16, bias=384.0, state=st)
     g1, _ = _run_gpu(engine, (7, 1, 7 | 16, 384.0), c1, delay=delay)
     g2, _ = _run_gpu(engine, (7, 1, 7 | 16, 384.0), c2, delay=delay)
+    g3, _ = _run_gpu(engine, (7, 1, 7 | 16, 384.0), c3, delay=delay)
     # with bias 384 one float32 ulp is 3e-5: compare after removing the bias exactly as the
     # s16 converter does (integer part), i.e. in units of 1/32768 full scale
-    for g, r in ((g1, r1), (g2, r2)):
+    for g, r in ((g1, r1), (g2, r2), (g3, r3)):
         err = (g.astype(np.float64) - r.astype(np.float64))
         assert np.abs(err).max() <= 2 * 3.0518e-5, np.abs(err).max()
 
@@ -103,10 +108,16 @@ def test_config4_downmix_mixed_blocks(engine, output):
     blksw[0] = 0                                    # stream 0: path B only
     blksw[1] = 1                                    # stream 1: all short (still path B)
     blksw[2, :, ::2] = 0                            # stream 2: alternate uniform / mixed blocks
+    coef2 = _coefs(rng, S, 2, 6)
+    blksw2 = (rng.random((S, 2, 6, 5)) < 0.3).astype(np.uint8)
     for lfe_out in (0, 16):
-        ref, _ = H.orc_xform(coef, blksw, 7, 1, output | lfe_out, bias=0.0, clev=0.5946, slev=0.5)
-        gpu, _ = _run_gpu(engine, (7, 1, output | lfe_out, 0.0), coef, blksw)
+        ref, st = H.orc_xform(coef, blksw, 7, 1, output | lfe_out, bias=0.0, clev=0.5946, slev=0.5)
+        gpu, delay = _run_gpu(engine, (7, 1, output | lfe_out, 0.0), coef, blksw)
         _check(gpu, ref, "5.1 -> %d" % (output | lfe_out))
+        # a second call continues from the tails the first one (run as whole-frame segments) left behind
+        ref2, _ = H.orc_xform(coef2, blksw2, 7, 1, output | lfe_out, bias=0.0, clev=0.5946, slev=0.5, state=st)
+        gpu2, _ = _run_gpu(engine, (7, 1, output | lfe_out, 0.0), coef2, blksw2, delay=delay)
+        _check(gpu2, ref2, "5.1 -> %d, second call" % (output | lfe_out))
 
 
 @pytest.mark.parametrize("acmod,output", [(0, 0), (0, 1), (0, 8), (0, 9), (1, 1), (1, 10), (2, 1), (2, 2), (3, 2),
