@@ -63,6 +63,7 @@ struct XformLaunch {
     float *delay;
     float *pcm;
     int n_streams, frames;
+    int blocks = 0;         // 0: frames x 6 blocks per stream; else exactly this many blocks (a52_imdct_512/256 hooks: 1)
     float bias;
     MixPlan plan;
     const int32_t *slot;    // optional per-stream state slot indices (device), see ac3mi_set_state_slots

@@ -185,8 +185,7 @@ void build_enc_tables(EncTables *t)
 int enc_config(int freq, int bitrate, int channels, EncConfig *c)
 {
     static const uint8_t acmod_of[6] = {1, 2, 3, 6, 7, 7};
-    static const int rates[3] = {48000, 44100, 32000};
-    static const int kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
+    const int *rates = kSampleRates, *kbps = kKbps;
     if (channels < 1 || channels > 6) return 0;
     c->nch = channels;
     c->acmod = acmod_of[channels - 1];
@@ -849,6 +848,32 @@ int ac3mi_encode_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, 
     if (xcos128) memcpy(xcos128, et.xcos, sizeof et.xcos);
     if (xsin128) memcpy(xsin128, et.xsin, sizeof et.xsin);
     if (window256) memcpy(window256, et.win, sizeof et.win);
+    return AC3MI_OK;
+}
+
+int ac3mi_encode_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *hth50x3, uint8_t *baptab64, uint8_t *bndsz50,
+                             uint16_t *sdecay4, uint16_t *fdecay4, uint16_t *sgain4, uint16_t *dbknee4, uint16_t *floor8,
+                             uint16_t *fgain8, uint16_t *freqs3, uint16_t *bitrate19)
+{
+    EncTables et;
+    build_enc_tables(&et);
+    if (window256) memcpy(window256, et.win, sizeof et.win);
+    if (latab256) memcpy(latab256, et.latab, sizeof et.latab);
+    if (hth50x3) memcpy(hth50x3, et.hth, sizeof et.hth);
+    if (baptab64) memcpy(baptab64, et.baptab, sizeof et.baptab);
+    if (bndsz50) memcpy(bndsz50, et.band_size, sizeof et.band_size);
+    for (int i = 0; i < 4; i++) {
+        if (sdecay4) sdecay4[i] = (uint16_t)enc_sdecay(i);
+        if (fdecay4) fdecay4[i] = (uint16_t)enc_fdecay(i);
+        if (sgain4) sgain4[i] = (uint16_t)enc_sgain(i);
+        if (dbknee4) dbknee4[i] = (uint16_t)enc_dbknee(i);
+    }
+    for (int i = 0; i < 8; i++) {
+        if (floor8) floor8[i] = (uint16_t)enc_floor(i);
+        if (fgain8) fgain8[i] = (uint16_t)enc_fgain(i);
+    }
+    for (int i = 0; i < 3; i++) if (freqs3) freqs3[i] = (uint16_t)kSampleRates[i];
+    for (int i = 0; i < 19; i++) if (bitrate19) bitrate19[i] = (uint16_t)kKbps[i];
     return AC3MI_OK;
 }
 

@@ -80,6 +80,12 @@ using namespace ac3mi;
 
 static std::mutex g_mu;
 static ac3mi_ctx *g_ctx;
+// Every a52_state_t, the encoder entry points and the MapTab converters share g_ctx (one HIP stream, its workspaces and
+// its error string).  liba52 is re-entrant per state and the ACM driver decodes different streams on different client
+// threads (src/AC3ACM.cpp:92-102), so calls that touch the context are serialised here; ac3enc itself is one stream
+// per process in the reference as well (ENC/ac3enc.cpp:78-87).
+static std::recursive_mutex g_call_mu;
+#define DROPIN_LOCK() std::lock_guard<std::recursive_mutex> dropin_lock_(g_call_mu)
 
 static ac3mi_ctx *dropin_ctx()
 {
@@ -127,6 +133,7 @@ a52_state_t *a52_init(uint32_t mm_accel)
     (void)mm_accel;                                     // no effect in the reference either (AC3ACM.cpp:2040-2043)
     ac3mi_ctx *ctx = dropin_ctx();
     if (!ctx) return nullptr;
+    DROPIN_LOCK();
     a52_state_t *st = (a52_state_t *)calloc(1, sizeof *st);
     if (!st) return nullptr;
     st->samples = (float *)calloc(256 * 12, sizeof(float));
@@ -205,6 +212,7 @@ void a52_dynrng(a52_state_t *st, level_t (*call)(level_t, void *), void *data)
 static int dropin_decode(a52_state_t *st)
 {
     ac3mi_ctx *ctx = dropin_ctx();
+    DROPIN_LOCK();
     ac3mi_decode_desc d;
     d.flags = st->req_flags;
     d.level = st->level_in;
@@ -242,6 +250,7 @@ void a52_free(a52_state_t *st)
 {
     if (!st) return;
     ac3mi_ctx *ctx = dropin_ctx();
+    DROPIN_LOCK();
     if (ctx) {
         ac3mi_dev_free(ctx, st->d_frame);
         ac3mi_dev_free(ctx, st->d_delay);
@@ -270,6 +279,7 @@ int ac3mi_AC3_encode_init(int freq, int bitrate, int channels)
     if (fb <= 0) return 0;
     ac3mi_ctx *ctx = dropin_ctx();
     if (!ctx) return 0;
+    DROPIN_LOCK();
     if (g_enc.ready) {
         ac3mi_dev_free(ctx, g_enc.d_pcm);
         ac3mi_dev_free(ctx, g_enc.d_last);
@@ -296,6 +306,7 @@ int ac3mi_AC3_encode_init(int freq, int bitrate, int channels)
 int ac3mi_AC3_encode_frame(unsigned char *dst, short *samples, unsigned char *chmap)
 {
     ac3mi_ctx *ctx = dropin_ctx();
+    DROPIN_LOCK();
     if (!ctx || !g_enc.ready) return 0;
     if (ac3mi_memcpy_h2d(ctx, g_enc.d_pcm, samples, (size_t)1536 * g_enc.nch * 2) != AC3MI_OK) return 0;
     if (ac3mi_encode_batch(ctx, &g_enc.desc, g_enc.d_pcm, chmap, g_enc.d_last, g_enc.d_csnr, g_enc.d_frame, g_enc.stride,
@@ -313,6 +324,7 @@ static void dropin_convert(const void *src, void *dst, int flags)
     int map[6];
     const int n_out = s16_channel_map(flags, map);
     if (!ctx || n_out <= 0) return;
+    DROPIN_LOCK();
     static float *d_src;
     static int16_t *d_dst;
     if (!d_src) {
@@ -333,7 +345,55 @@ ConvertProc MapTab[2][6][6] = {
 };
 #undef CV
 
-int IsMMX(void) { return 1; }                            // as the x64 build (AC3ASM.asm:199-204)
+bool IsMMX(void) { return true; }                        // as the x64 build (AC3ASM.asm:199-204)
+
+// ---- secondary liba52 entry points (liba52/a52_internal.h:106-120) --------------------------------------
+// Host pointers in and out like liba52's: one transform = one launch of the batched transform kernel on a single
+// mono plane (the per-transform hook the reference's own tools use; not a fast path).
+
+void a52_imdct_init(uint32_t mm_accel) { (void)mm_accel; (void)dropin_ctx(); }      // tables are built with the context
+
+static void dropin_imdct(sample_t *data, sample_t *delay, sample_t bias, int short_block)
+{
+    ac3mi_ctx *ctx = dropin_ctx();
+    if (!ctx || !data || !delay) return;
+    DROPIN_LOCK();
+    static float *d_buf;                                 // [256 coefficients | 256 PCM | 128 overlap | flag]
+    if (!d_buf) d_buf = (float *)ac3mi_dev_alloc(ctx, (256 + 256 + 128 + 4) * sizeof(float));
+    if (!d_buf) return;
+    const uint8_t sw = short_block ? 1 : 0;
+    XformLaunch L;
+    if (build_mix_plan(1, 0, AC3MI_MONO, &L.plan) != AC3MI_OK) return;
+    ac3mi_memcpy_h2d(ctx, d_buf, data, 256 * sizeof(float));
+    ac3mi_memcpy_h2d(ctx, d_buf + 512, delay, 128 * sizeof(float));      // delay[128..255] is dead in liba52 (imdct.c:276-292)
+    ac3mi_memcpy_h2d(ctx, d_buf + 640, &sw, 1);
+    L.coef = d_buf;
+    L.blksw = (const uint8_t *)(d_buf + 640);
+    L.delay = d_buf + 512;
+    L.pcm = d_buf + 256;
+    L.n_streams = 1;
+    L.frames = 1;
+    L.blocks = 1;
+    L.bias = bias;
+    L.slot = nullptr;
+    L.delay_stride = 128;
+    if (hipSetDevice(ctx->device) != hipSuccess || launch_xform(ctx->tab, L, ctx->stream) != hipSuccess) return;
+    ac3mi_memcpy_d2h(ctx, data, d_buf + 256, 256 * sizeof(float));
+    ac3mi_memcpy_d2h(ctx, delay, d_buf + 512, 128 * sizeof(float));
+}
+
+void a52_imdct_512(sample_t *data, sample_t *delay, sample_t bias) { dropin_imdct(data, delay, bias, 0); }
+void a52_imdct_256(sample_t *data, sample_t *delay, sample_t bias) { dropin_imdct(data, delay, bias, 1); }
+
+// pure host arithmetic, shared with the kernels (a52_levels.h)
+int a52_downmix_init(int input, int flags, level_t *level, level_t clev, level_t slev)
+{
+    return a52_downmix_init_hd(input, flags, level, clev, slev);
+}
+int a52_downmix_coeff(level_t *coeff, int acmod, int output, level_t level, level_t clev, level_t slev)
+{
+    return a52_downmix_coeff_hd(coeff, acmod, output, level, clev, slev);
+}
 
 }  // extern "C"
 

@@ -22,6 +22,7 @@
 // with the reference's expressions.
 #include "ac3mi_internal.h"
 #include "wave_ops.h"
+#include "spec_tables.h"
 
 namespace ac3mi {
 
@@ -474,8 +475,9 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
         WAVE_SYNC();
         // fixed allocation codes (:861-879)
         const int sdecaycod = 2, fdecaycod = 1, fgaincod = 4;
-        const int sdecay = (15 + 2 * sdecaycod) >> P.halfrate, fdecay = (63 + 20 * fdecaycod) >> P.halfrate;
-        const int sgain = 0x4d8, dbknee = 0x900, fgain = 128 * (fgaincod + 1);
+        constexpr int sgaincod = 1, dbkneecod = 2;
+        const int sdecay = enc_sdecay(sdecaycod) >> P.halfrate, fdecay = enc_fdecay(fdecaycod) >> P.halfrate;
+        const int sgain = enc_sgain(sgaincod), dbknee = enc_dbknee(dbkneecod), fgain = enc_fgain(fgaincod);
         const int bndend = L.t.band_of_bin[n - 1] + 1;
         for (uint32_t m = starts; m; m &= m - 1)
             mask_row_wave(L.t, L.mask[__builtin_ctz(m)], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
@@ -487,14 +489,15 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
     }
     WAVE_SYNC();
 
-    // ---- results: the pack kernel wants the masks minus the floor (0x1f0) ----
+    // ---- results: the pack kernel wants the masks minus the floor (floorcod 4: 0x1f0) ----
+    static_assert(enc_floor(4) == 0x1f0 && enc_sgain(1) == 0x4d8 && enc_dbknee(2) == 0x900, "ENC/ac3tab.h:151-161");
 #pragma unroll
     for (int b = 0; b < 6; b++)
         *reinterpret_cast<uint32_t *>(P.eexp + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) =
             *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
     for (int i = lane; i < 6 * 50; i += 64) {
         const int b = i / 50, k = i - 50 * b;
-        P.emask[((fidx * 6 + b) * nch + ch) * 50 + k] = (int16_t)(L.mask[b][k] - 0x1f0);
+        P.emask[((fidx * 6 + b) * nch + ch) * 50 + k] = (int16_t)(L.mask[b][k] - enc_floor(4));
     }
     if (lane < 6) P.strat[(fidx * 6 + lane) * nch + ch] = L.strat[lane];
     if (lane == 0) P.ebits[fidx * nch + ch] = exp_bits;

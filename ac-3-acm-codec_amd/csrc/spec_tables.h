@@ -50,6 +50,18 @@ static const uint8_t kLaRun[65] = {
     46
 };
 
+// encoder form of the bit-allocation parameter codes (ENC/ac3tab.h:143-165) and the rate tables
+// (ENC/ac3tab.h:3-12); constexpr so that the kernels fold them and ac3mi_encode_spec_tables() hands
+// out the very values the kernels use
+constexpr int enc_sdecay(int cod) { return 15 + 2 * cod; }
+constexpr int enc_fdecay(int cod) { return 63 + 20 * cod; }
+constexpr int enc_fgain(int cod) { return 128 * (cod + 1); }
+constexpr int enc_sgain(int cod) { return cod == 0 ? 0x540 : cod == 1 ? 0x4d8 : cod == 2 ? 0x478 : 0x410; }
+constexpr int enc_dbknee(int cod) { return cod == 0 ? 0 : 0x500 + 0x200 * cod; }
+constexpr int enc_floor(int cod) { return cod < 5 ? 0x2f0 - 0x40 * cod : cod == 5 ? 0x170 : cod == 6 ? 0x0f0 : 0xf800; }
+static const int kSampleRates[3] = {48000, 44100, 32000};
+static const int kKbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
+
 static inline void build_logadd(uint8_t *tab256)
 {
     int n = 0;

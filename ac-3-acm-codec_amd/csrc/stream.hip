@@ -477,8 +477,9 @@ int ac3mi_stream_framesize(const ac3mi_wavefmt *f)
 {
     // ac3_framesize, src/AC3ACM.cpp:432-488
     if (!f) return 0;
+    // 24 kHz and 12 kHz hash to column 3 (the kbps column) exactly as in the reference: a 24 kHz / 384 kbps stream is
+    // given 2 x 384 = 768 bytes per frame
     const int spsindex = (int)(f->samples_per_sec >> 6) & 3;
-    if (spsindex == 3) return 0;                                    // cannot happen for the nine valid rates
     if (f->block_align > 1)
         for (int i = 0; i < 19; i++)
             if (f->block_align == k_framesizes[i][spsindex] * 2) return f->block_align;

@@ -30,7 +30,8 @@ struct XformParams {
     const float2 *tw_short;
     const float *window;
     int n_chains;
-    int frames;
+    int frames;                 // stride of a stream in frames (coefficients, PCM, block-switch flags)
+    int nblk;                   // blocks per chain (frames * 6 but for the single-transform hooks)
     int n_in, n_out, nfchans, in_lfe;
     float bias;
     int8_t mix[6][6];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             }
     }
 
-    const int nblk = P.frames * 6;
+    const int nblk = P.nblk;
     const int b_lo = seg * P.seg_blocks, b_hi = b_lo + P.seg_blocks < nblk ? b_lo + P.seg_blocks : nblk;
     // The overlap state is read and rewritten in place, and the segments of a chain run in groups (possibly workgroups)
     // of their own with nothing ordering them: so the group that READS the chain's state (segment 0) is also the one
@@ -295,6 +296,7 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     P.window = tab.window;
     P.n_chains = L.n_streams * L.plan.n_out;
     P.frames = L.frames;
+    P.nblk = L.blocks > 0 ? L.blocks : L.frames * 6;
     P.n_in = L.plan.n_in;
     P.n_out = L.plan.n_out;
     P.nfchans = L.plan.nfchans;

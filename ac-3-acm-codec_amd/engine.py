@@ -87,6 +87,14 @@ class Engine:
         if rc != 0:
             raise capi.AC3MIError("ac3mi error %d: %s" % (rc, self.lib.ac3mi_last_error(self.ctx).decode()))
 
+    def _drain_torch(self, wait_torch):
+        """The engine launches on its own (non-blocking) HIP streams.  Everything torch has queued for the buffers of a
+        call - the producers of its inputs AND the fills of outputs allocated inside the call (torch.zeros) - must have
+        finished before the engine touches them, so the drain comes after every allocation, right before the launch."""
+        if wait_torch:
+            import torch
+            torch.cuda.synchronize(self.device)
+
     def sync(self):
         self._check(self.lib.ac3mi_sync(self.ctx))
         self._keep.clear()
@@ -115,8 +123,6 @@ class Engine:
         The engine runs on its own HIP stream: with wait_torch the call first drains torch's
         stream (the inputs were produced there); call sync() before reading the result."""
         import torch
-        if wait_torch:
-            torch.cuda.synchronize(self.device)
         n_in, n_out = self.planes(desc)
         S, F = coeffs.shape[0], coeffs.shape[1]
         assert coeffs.dtype == torch.float32 and coeffs.is_contiguous() and coeffs.is_cuda
@@ -127,6 +133,7 @@ class Engine:
         if out is None:
             out = torch.empty((S, F, 6, n_out, 256), dtype=torch.float32, device=coeffs.device)
         c = desc.c()
+        self._drain_torch(wait_torch)
         self._check(self.lib.ac3mi_imdct_batch(self.ctx, ctypes.byref(c), coeffs.data_ptr(),
                                                blksw.data_ptr() if blksw is not None else None,
                                                delay.data_ptr(), out.data_ptr(), S, F))
@@ -144,8 +151,6 @@ class Engine:
         """frames [S][F][stride] u8 (stride multiple of 4), delay [S][n_out][128] f32, lfsr [S] i16/u16
         (both updated in place) -> (pcm [S][F][6][n_out][256] f32, status [S][F] i32[, taps dict])."""
         import torch
-        if wait_torch:
-            torch.cuda.synchronize(self.device)
         n_out, out_flags = self.decode_planes(desc)
         S, F, stride = frames.shape
         assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.is_cuda
@@ -166,10 +171,10 @@ class Engine:
                 "exp": torch.zeros((S, F, 6, 7, 256), dtype=torch.uint8, device=dev),
                 "bap": torch.zeros((S, F, 6, 7, 256), dtype=torch.int8, device=dev),
             }
-            torch.cuda.synchronize(self.device)
             tp = capi.DecodeTapsC(tdict["coef"].data_ptr(), tdict["blksw"].data_ptr(), tdict["exp"].data_ptr(),
                                   tdict["bap"].data_ptr())
         c = desc.c()
+        self._drain_torch(wait_torch or taps)
         self._check(self.lib.ac3mi_decode_batch(self.ctx, ctypes.byref(c), frames.data_ptr(), stride, S, F,
                                                 delay.data_ptr(), lfsr.data_ptr(), out.data_ptr(),
                                                 status.data_ptr(), ctypes.byref(tp) if tp else None))
@@ -182,8 +187,6 @@ class Engine:
         """ac3mi_decode_s16_batch: like decode_batch at level 1 / bias 384 with the reference's s16 converter folded into
         the transform -> (pcm [S][F][6][256][n_out] i16 in WAVE channel order, status [S][F] i32)."""
         import torch
-        if wait_torch:
-            torch.cuda.synchronize(self.device)
         n_out, _ = self.decode_planes(desc)
         S, F, stride = frames.shape
         assert frames.dtype == torch.uint8 and frames.is_contiguous() and frames.is_cuda
@@ -195,6 +198,7 @@ class Engine:
         if status is None:
             status = torch.zeros((S, F), dtype=torch.int32, device=dev)
         c = desc.c()
+        self._drain_torch(wait_torch)
         self._check(self.lib.ac3mi_decode_s16_batch(self.ctx, ctypes.byref(c), frames.data_ptr(), stride, S, F,
                                                     delay.data_ptr(), lfsr.data_ptr(), out.data_ptr(), status.data_ptr()))
         self._keep.append((frames, delay, lfsr, out, status))
@@ -218,8 +222,6 @@ class Engine:
         """frames [S][F][in_stride] u8 -> re-encoded frames [S][F][out_stride] u8 (+ status [S][F]); the state arrays
         are those of decode_batch (delay, lfsr) and encode_batch (last, csnroffst), all updated in place."""
         import torch
-        if wait_torch:
-            torch.cuda.synchronize(self.device)
         S, F, in_stride = frames.shape
         fb = enc.frame_bytes()
         stride = (fb + 3) & ~3
@@ -230,6 +232,7 @@ class Engine:
             status = torch.zeros((S, F), dtype=torch.int32, device=dev)
         cm = (ctypes.c_uint8 * 8)(*(list(chmap) + [0] * 8)[:8])
         dc, ec = dec.c(), enc.c()
+        self._drain_torch(wait_torch)
         self._check(self.lib.ac3mi_transcode_batch(self.ctx, ctypes.byref(dc), ctypes.byref(ec), frames.data_ptr(), in_stride, S, F,
                                                    delay.data_ptr(), lfsr.data_ptr(), cm, last.data_ptr(), csnroffst.data_ptr(),
                                                    out.data_ptr(), stride, status.data_ptr()))
@@ -240,8 +243,6 @@ class Engine:
         """pcm [S][F][1536][nch] s16, chmap = nch ints, last [S][nch][256] s16, csnroffst [S] i32 (both
         updated in place) -> frames [S][F][stride] u8 (stride = frame bytes rounded up to 4)[, taps dict]."""
         import torch
-        if wait_torch:
-            torch.cuda.synchronize(self.device)
         fb = desc.frame_bytes()
         if fb <= 0:
             raise capi.AC3MIError("AC3_encode_init would reject %r" % (desc,))
@@ -268,10 +269,10 @@ class Engine:
                 "exp_strategy": torch.zeros((S, F, 6, nch), dtype=torch.uint8, device=dev),
                 "snroffst": torch.zeros((S, F, 2), dtype=torch.int32, device=dev),
             }
-            torch.cuda.synchronize(self.device)
             tp = capi.EncodeTapsC(*(tdict[k].data_ptr() for k in ("mdct", "exponent", "exp_samples", "encoded_exp",
                                                                    "bap", "exp_strategy", "snroffst")))
         c = desc.c()
+        self._drain_torch(wait_torch or taps)
         self._check(self.lib.ac3mi_encode_batch(self.ctx, ctypes.byref(c), pcm.data_ptr(), cm, last.data_ptr(),
                                                 csnroffst.data_ptr(), out.data_ptr(), stride, S, F,
                                                 ctypes.byref(tp) if tp else None))

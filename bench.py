@@ -7,8 +7,10 @@ through IMDCT-512 + KBD window + overlap-add (the synthesis stage of a52_block).
 One "step" = one pass of ac3mi_imdct_batch over that batch, inputs resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`; every rank owns
-   its own 65536 streams - independent streams shard with no data-path collective: weak scaling)
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or started plainly, in which case this process only
+  spawns N child ranks of itself (before touching the GPU), one per device, and relays rank 0's line.
+  Every rank owns its own 65536 streams - independent streams shard with no data-path collective: weak scaling.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
 """
@@ -160,6 +162,74 @@ def measured_traffic(frames):
     return best
 
 
+def instruction_mix():
+    """Per-frame instruction counts of the engine kernels from the committed rocprofv3 PMC summary
+    (profiles/*_instruction_mix.json, newest by name; recipe profiles/run_r02.sh).  None if absent."""
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted(fn for fn in (os.listdir(pdir) if os.path.isdir(pdir) else []) if fn.endswith("_instruction_mix.json"))
+    if not names:
+        return None
+    try:
+        d = json.load(open(os.path.join(pdir, names[-1])))
+        d["file"] = "profiles/" + names[-1]
+        return d
+    except (OSError, ValueError):
+        return None
+
+
+N_SIMD = 256 * 4           # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def leg_rooflines(name, nbytes, fps, probe_ginst, mix):
+    """The two ceilings of a secondary leg.  hbm: algorithmic bytes x frames/s against 8 TB/s.
+    valu_issue: VALU instructions per frame (committed PMC summary, named in `source`) x frames/s against what all SIMDs
+    issue, measured by ac3mi_probe_valu_rate in this very run."""
+    out = {"hbm": {"bound": "hbm", "achieved": nbytes * fps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": nbytes * fps / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": nbytes}}
+    leg = (mix or {}).get("legs", {}).get(name)
+    if leg and probe_ginst:
+        valu = sum(mix["kernels"][k]["valu_per_frame"] for k in leg)
+        salu = sum(mix["kernels"][k].get("salu_per_frame", 0) for k in leg)
+        peak = probe_ginst * N_SIMD                  # 10^9 instructions/s, whole chip
+        out["valu_issue"] = {"bound": "valu_issue", "achieved": valu * fps / 1e9, "peak": peak, "unit": "Ginst/s",
+                             "frac": valu * fps / 1e9 / peak, "valu_per_frame": valu, "salu_per_frame": salu,
+                             "kernels": leg, "source": mix.get("file"),
+                             "peak_source": "ac3mi_probe_valu_rate of this run x %d SIMDs" % N_SIMD}
+    else:
+        out["valu_issue"] = None
+    return out
+
+
+_CRC_TAB = None
+
+
+def ac3_crc_ok(frames):
+    """Both CRCs of every AC-3 frame (numpy, host): crc1 covers the first 5/8 of the frame, crc2 the whole frame
+    (ENC/ac3enc.cpp:1599-1638); a frame is intact when the CRC-16 (poly 0x8005) of bytes [2, 5/8) and of bytes [2, end)
+    are both zero.  frames: [n][frame_bytes] uint8.  Returns the number of frames failing either check."""
+    import numpy as np
+    global _CRC_TAB
+    if _CRC_TAB is None:
+        t = np.zeros(256, np.uint32)
+        for n in range(256):
+            c = n << 8
+            for _ in range(8):
+                c = ((c << 1) ^ 0x8005) & 0xffff if c & 0x8000 else (c << 1) & 0xffff
+            t[n] = c
+        _CRC_TAB = t
+    n, fb = frames.shape
+    words = fb // 2
+    fs58 = ((words >> 1) + (words >> 3)) * 2          # bytes covered by crc1 (incl. the sync word, which is skipped)
+    crc = np.zeros(n, np.uint32)
+    bad1 = None
+    cols = np.ascontiguousarray(frames.T)              # [fb][n]: one contiguous row per byte position
+    for i in range(2, fb):
+        crc = (_CRC_TAB[(cols[i] ^ (crc >> 8)) & 0xff] ^ (crc << 8)) & 0xffff
+        if i == fs58 - 1:
+            bad1 = crc != 0
+    return int(np.count_nonzero(bad1 | (crc != 0)))
+
+
 def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     """Whole-path numbers for the other BASELINE configs on the same batch size (frames resident in HBM):
     configs[2] encode (s16 PCM -> frames), bitstream decode (frames -> float PCM, both kernels) and
@@ -186,7 +256,10 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
     lfsr = torch.ones((S,), dtype=torch.int16, device=dev)
     out = torch.empty((S, 1, 6, 6, 256), dtype=torch.float32, device=dev)
+    # one status array per leg: each leg's frame verdicts are read after all legs have run
     status = torch.zeros((S, 1), dtype=torch.int32, device=dev)
+    status16 = torch.zeros((S, 1), dtype=torch.int32, device=dev)
+    status_tc = torch.zeros((S, 1), dtype=torch.int32, device=dev)
     s16 = torch.empty((S, 6 * 256, 6), dtype=torch.int16, device=dev)
     frames2 = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
     chmap = (0, 2, 1, 4, 5, 3)
@@ -199,9 +272,11 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
         eng.decode_batch(dec, frames, delay, lfsr, out=out, status=status, wait_torch=False)
 
     out16 = torch.empty((S, 1, 6, 256, 6), dtype=torch.int16, device=dev)
+    delay16 = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+    lfsr16 = torch.ones((S,), dtype=torch.int16, device=dev)
 
     def do_dec16():
-        eng.decode_s16_batch(dec, frames, delay, lfsr, out=out16, status=status, wait_torch=False)
+        eng.decode_s16_batch(dec, frames, delay16, lfsr16, out=out16, status=status16, wait_torch=False)
 
     def do_cvt():
         eng._check(eng.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(eng.ctx), ctypes.c_void_p(out.data_ptr()),
@@ -213,7 +288,7 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     csnr2 = torch.full((S,), 40, dtype=torch.int32, device=dev)
 
     def do_transcode():
-        eng.transcode_batch(dec, enc, frames, delay2, lfsr2, chmap, last2, csnr2, out=frames2, status=status, wait_torch=False)
+        eng.transcode_batch(dec, enc, frames, delay2, lfsr2, chmap, last2, csnr2, out=frames2, status=status_tc, wait_torch=False)
 
     # BASELINE configs[3]: mixed short/long blocks (a quarter of the channel-blocks switched) with the 5.1 -> 2.0
     # downmix folded into the transform: 5 of the 6 planes in (liba52 drops the LFE), 2 planes out, 2 overlap tails
@@ -248,14 +323,29 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
         res[name] = {"frames_per_s_per_gpu": fps, "ms_per_pass": ms, "algorithmic_GBps": nbytes * fps / 1e9,
                      "hbm_frac": nbytes * fps / 1e9 / HBM_PEAK_GBS, "realtime_x": fps * 0.032,
                      "algorithmic_bytes_per_frame": nbytes}
-    ok = int((status & 0x1ff).max().item()) == 0
-    res["decode"]["all_frames_ok"] = ok
-    res["_frames"] = frames[:64].cpu().numpy()          # for the CPU rates beside these legs (dropped from the line)
     # the issue ceiling of the instruction-bound kernels: plain VALU instructions per second and SIMD, chip-wide load
     rate = eng.probe_valu_rate()
     res["valu_probe"] = {"ginst_per_s_per_simd": rate,
                          "note": "plain 32-bit VALU instructions one SIMD sustains with all SIMDs busy (8 wavefronts each); "
-                                 "decode / encode kernels are priced against this in DESIGN.md"}
+                                 "the valu_issue rooflines of the legs are priced against this x %d SIMDs" % N_SIMD}
+    mix = instruction_mix()
+    for name in ("encode", "decode", "decode_s16", "transcode", "transform_downmix_mixed_blocks"):
+        res[name]["roofline"] = leg_rooflines(name, res[name]["algorithmic_bytes_per_frame"], res[name]["frames_per_s_per_gpu"], rate, mix)
+    # ---- untimed epilogue: every leg's verdict on the whole batch, from its own buffers ----
+    eng.sync()
+    torch.cuda.synchronize(dev)
+    res["decode"]["all_frames_ok"] = int((status & 0x1ff).max().item()) == 0
+    res["decode_s16"]["all_frames_ok"] = int((status16 & 0x1ff).max().item()) == 0
+    res["transcode"]["all_frames_decoded_ok"] = int((status_tc & 0x1ff).max().item()) == 0
+    enc_host = frames.cpu().numpy().reshape(S, -1)[:, :fb]
+    tc_host = frames2.cpu().numpy().reshape(S, -1)[:, :fb]
+    res["encode"]["frames_failing_crc"] = ac3_crc_ok(enc_host)
+    res["transcode"]["frames_failing_crc"] = ac3_crc_ok(tc_host)
+    res["encode"]["all_frames_ok"] = res["encode"]["frames_failing_crc"] == 0
+    res["transcode"]["all_frames_ok"] = res["transcode"]["frames_failing_crc"] == 0 and res["transcode"]["all_frames_decoded_ok"]
+    if rank == 0:
+        res["encode"]["bit_exact_vs_oracle"] = check_against_oracle(pkg, eng, dev, enc, dec, chmap, pcm)
+    res["_frames"] = enc_host[:64].reshape(64, 1, fb).copy()      # for the CPU rates beside these legs (dropped from the line)
     if os.environ.get("AC3MI_BENCH_MILLION") == "1":
         res["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, frames)
     if dist is None:           # host-side work on up to 16 threads: single-process runs only
@@ -263,6 +353,57 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
                    "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
     return res
+
+
+def check_against_oracle(pkg, eng, dev, enc, dec, chmap, pcm, n_enc=4096, n_dec=256):
+    """BASELINE configs[2]'s "bit-exact check" at bench size, untimed.  The timed legs carry stream state from pass to
+    pass, so this runs ONE fresh-state pass over the first n_enc one-frame streams of the batch (encoder history 0,
+    csnroffst 40, as AC3_encode_init leaves a stream) and compares every frame byte for byte with the CPU oracle's
+    encoding of the same PCM; the first n_dec of those frames are then decoded to s16 by the engine (fresh decoder state)
+    and by the oracle (<= 1 step apart: the float PCM may differ by one ulp at bias 384).  The oracle is the checker only."""
+    import ctypes
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import _harness as H
+    O = H.orc()
+    O.orc_ac3enc_encode_frames.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, H.i16p, ctypes.c_int, H.u8p, H.u8p]
+    S = pcm.shape[0]
+    n_enc, n_dec = min(n_enc, S), min(n_dec, n_enc, S)
+    fb = enc.frame_bytes()
+    sub = pcm[:n_enc].contiguous()
+    last = torch.zeros((n_enc, 6, 256), dtype=torch.int16, device=dev)
+    csnr = torch.full((n_enc,), 40, dtype=torch.int32, device=dev)
+    got = eng.encode_batch(enc, sub, chmap, last, csnr)
+    eng.sync()
+    got_host = got.cpu().numpy().reshape(n_enc, -1)[:, :fb]
+    src = np.ascontiguousarray(sub.cpu().numpy().reshape(n_enc, 1536 * 6))
+    cm = (ctypes.c_uint8 * 8)(*H.CHMAP6)
+    want = np.zeros((n_enc, fb), np.uint8)
+
+    def one(i):
+        return O.orc_ac3enc_encode_frames(48000, 384000, 6, H.P(src[i], H.i16p), 1, cm, H.P(want[i], H.u8p))
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        rcs = list(ex.map(one, range(n_enc)))
+    enc_mismatch = int(np.count_nonzero((want != got_host).any(axis=1))) + sum(1 for r in rcs if r)
+    delay = torch.zeros((n_dec, 6, 128), dtype=torch.float32, device=dev)
+    lfsr = torch.ones((n_dec,), dtype=torch.int16, device=dev)
+    out16, st = eng.decode_s16_batch(dec, got[:n_dec].contiguous(), delay, lfsr)
+    eng.sync()
+    got16 = out16.cpu().numpy().reshape(n_dec, 6, 256, 6)
+    dec_ok = int((st & 0x1ff).max().item()) == 0
+    worst = 0
+    ref16 = np.zeros((256, 6), np.int16)
+    for i in range(n_dec):
+        pcmf, errs, oflags = H.orc_decode(got_host[i:i + 1], 7 | 16 | 32, 1.0, 384.0)
+        dec_ok = dec_ok and errs == 0
+        for b in range(6):
+            O.orc_convert_s16(H.P(np.ascontiguousarray(pcmf[0, b]), H.fp), H.P(ref16, H.i16p), oflags)
+            worst = max(worst, int(np.abs(got16[i, b].astype(np.int32) - ref16.astype(np.int32)).max()))
+    return {"encode_frames_checked": n_enc, "encode_frames_differing": enc_mismatch,
+            "decode_s16_frames_checked": n_dec, "decode_s16_max_abs_step": worst,
+            "ok": enc_mismatch == 0 and worst <= 1 and dec_ok,
+            "note": "fresh-state pass over the first streams of the batch vs oracle/liborc.so (untimed epilogue)"}
 
 
 def million_stream_transcode(pkg, eng, dev, frames, n_streams=1 << 20, passes=2):
@@ -327,6 +468,57 @@ def stream_layer_timing(pkg, eng, frames, rounds=3):
                     "H2D, decode + transform + s16 kernels, D2H, all inside the timed call (PCIe-inclusive)"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` started without a launcher: spawn N ranks of this script, one per device, and relay
+    rank 0's line.  Runs BEFORE anything touches the GPU in this process (the children are fresh processes, never an exec
+    from a process that initialised HIP); the parent only waits and collects."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def launch_check():
+    """--launch-check: the rendezvous, barrier and MAX / SUM reductions of the N-rank path over gloo, no GPU and no
+    engine (tests/test_bench_launcher.py runs it on CPU with world size 2)."""
+    import torch
+    import torch.distributed as dist
+    sh = importlib_pkg().sharding
+    rank, local_rank, world = sh.env_ranks()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    lo, hi = sh.shard(FRAMES_PER_GPU * world, world, rank)
+    tmax, = sh.reduce_max([0.001 * (rank + 1)], dist if world > 1 else None)
+    total, = sh.reduce_sum([hi - lo], dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "streams_total": int(total), "max_time": tmax,
+                          "local_rank": local_rank}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def importlib_pkg():
+    import importlib
+    return importlib.import_module("ac-3-acm-codec_amd")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,7 +527,14 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary decode/encode/transcode timings")
+    ap.add_argument("--launch-check", action="store_true", help="N-rank rendezvous and reductions only (gloo, no GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.launch_check:
+        launch_check()
+        return
 
     import importlib
     import torch
@@ -366,6 +565,9 @@ def main():
     desc = pkg.XformDesc(acmod=7, lfeon=1, output=7 | 16, bias=0.0)
 
     S = args.frames
+    # this rank's contiguous shard of the job's S x world independent streams (no data-path collective)
+    lo, hi = pkg.sharding.shard(S * world, world, rank)
+    assert hi - lo == S
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     coef = torch.randn((S, 1, 6, N_CH, 256), device=dev, generator=g, dtype=torch.float32) * (2.0 ** -8)
     delay = torch.zeros((S, N_CH, 128), device=dev, dtype=torch.float32)
@@ -435,6 +637,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(S),
+                "traffic_source": "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch size "
+                                  "(profiles/*_hbm_traffic.json), not collected in this run",
                 "kernel": "ac3mi::xform_kernel<false, 4, false>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,

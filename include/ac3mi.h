@@ -254,6 +254,14 @@ int ac3mi_encode_frame_bytes(const ac3mi_encode_desc *desc);
 /* the Q15 tables AC3_encode_init builds on the host (fft_init, xcos1/xsin1) and the window */
 int ac3mi_encode_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128, int16_t *window256);
 
+/* the encoder's spec tables as the kernels use them, in the reference's own form (src/ac3enc/ac3tab.h:3-171:
+ * ac3_window, latab (first 256 entries), hth[50][3], baptab, bndsz, sdecaytab, fdecaytab, sgaintab, dbkneetab, floortab,
+ * fgaintab, ac3_freqs, ac3_bitratetab); any pointer may be NULL.  tests/test_oracle_golden.py checks them against
+ * tests/golden/ac3tab.npz, which is frozen from the reference's header. */
+int ac3mi_encode_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *hth50x3, uint8_t *baptab64, uint8_t *bndsz50,
+                             uint16_t *sdecay4, uint16_t *fdecay4, uint16_t *sgain4, uint16_t *dbknee4, uint16_t *floor8,
+                             uint16_t *fgain8, uint16_t *freqs3, uint16_t *bitrate19);
+
 /* d_pcm        [n_streams][frames_per_stream][1536][channels] s16 interleaved (AC3_encode_frame's `samples`)
  * chmap        HOST array, `channels` entries: input slot of coded channel ch (AC3_encode_frame's `chmap`;
  *              the driver passes {0,2,1,4,5,3} for 6-channel WAVE order, src/AC3ACM.cpp:1631-1662)

@@ -22,6 +22,7 @@
 #ifndef AC3MI_DROPIN_H
 #define AC3MI_DROPIN_H
 
+#include <stdbool.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -47,7 +48,24 @@ int ac3mi_AC3_encode_frame(unsigned char *dst, short *samples, unsigned char *ch
 /* float (bias 384) -> s16 interleaved WAVE order, 256 samples; src = a52_samples() */
 typedef void (*ConvertProc)(const void *src, void *dst, int flags);
 extern ConvertProc MapTab[2][6][6];
-int IsMMX(void);
+bool IsMMX(void);                      /* extern "C" bool IsMMX(), src/AC3ACM.cpp:90 */
+
+/* Secondary liba52 entry points (a52dec-0.7.5-cvs/liba52/a52_internal.h:106-120), same argument meaning.
+ * a52_imdct_512 / a52_imdct_256: data[256] coefficients in, PCM out in place; delay[256] overlap plane of which liba52
+ * reads and writes [0,128) only (imdct.c:276-292), and so does this library.  One call = one single-plane launch of the
+ * batched transform kernel: a per-transform hook, not a fast path.  a52_downmix_init / a52_downmix_coeff are the host
+ * arithmetic of liba52/downmix.c:34-330, bit-identical floats.  Not provided: a52_bit_allocate (needs liba52's private
+ * state struct), a52_downmix / a52_upmix (the engine mixes in the frequency domain inside the transform kernel),
+ * a52_bitstream_* (the bit reader lives in LDS). */
+void a52_imdct_init(uint32_t mm_accel);
+void a52_imdct_512(sample_t *data, sample_t *delay, sample_t bias);
+void a52_imdct_256(sample_t *data, sample_t *delay, sample_t bias);
+int a52_downmix_init(int input, int flags, level_t *level, level_t clev, level_t slev);
+int a52_downmix_coeff(level_t *coeff, int acmod, int output, level_t level, level_t clev, level_t slev);
+
+/* Threading: every call of this header that reaches the GPU is serialised on one process-wide lock (all states share one
+ * engine context).  Different a52_state_t may be used from different threads, as with liba52; the encoder is one stream
+ * per process, as in the reference (src/ac3enc/ac3enc.cpp:78-87). */
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,18 @@ static const uint8_t bap_of_addr[64] = {     /* A/52 baptab (ac3tab.h:135-143) *
     15, 15, 15, 15, 15, 15, 15, 15
 };
 
+/* bit-allocation parameter codes -> values (ac3tab.h:143-165) and the rate tables (ac3tab.h:3-12);
+ * file scope so that orc_ac3enc_spec_tables() hands out exactly what the code below uses */
+static const uint16_t slow_gain[4] = { 0x540, 0x4d8, 0x478, 0x410 };
+static const uint16_t db_knee[4] = { 0x000, 0x700, 0x900, 0xb00 };
+static const uint16_t floor_of[8] = { 0x2f0, 0x2b0, 0x270, 0x230, 0x1f0, 0x170, 0x0f0, 0xf800 };
+static const uint16_t sample_rates[3] = { 48000, 44100, 32000 };
+static const uint16_t kbps_of[19] = { 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320,
+                                      384, 448, 512, 576, 640 };
+static int slow_decay(int cod) { return 15 + 2 * cod; }             /* sdecaytab */
+static int fast_decay(int cod) { return 63 + 20 * cod; }            /* fdecaytab */
+static int fast_gain(int cod) { return 128 * (cod + 1); }           /* fgaintab */
+
 /* ac3enc.cpp:428-439 */
 static int16_t q15_trunc(float a)
 {
@@ -155,6 +167,31 @@ void orc_ac3enc_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, i
     memcpy(xcos128, xcos_q15, sizeof xcos_q15);
     memcpy(xsin128, xsin_q15, sizeof xsin_q15);
     memcpy(crc256, crc_tab, sizeof crc_tab);
+}
+
+/* the spec tables as this file uses them, in the reference's own form (ac3tab.h:3-171), for the
+ * fixture check against tests/golden/ac3tab.npz (frozen from the reference's header) */
+void orc_ac3enc_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *hth50x3, uint8_t *baptab64,
+                            uint8_t *bndsz50, uint16_t *sdecay4, uint16_t *fdecay4, uint16_t *sgain4,
+                            uint16_t *dbknee4, uint16_t *floor8, uint16_t *fgain8, uint16_t *freqs3,
+                            uint16_t *bitrate19)
+{
+    int i;
+    enc_build_tables();
+    memcpy(window256, win_q15, sizeof win_q15);
+    memcpy(latab256, logadd, sizeof logadd);
+    memcpy(hth50x3, hear_thr, sizeof hear_thr);
+    memcpy(baptab64, bap_of_addr, sizeof bap_of_addr);
+    memcpy(bndsz50, band_size, sizeof band_size);
+    for (i = 0; i < 4; i++) {
+        sdecay4[i] = (uint16_t)slow_decay(i);
+        fdecay4[i] = (uint16_t)fast_decay(i);
+        sgain4[i] = slow_gain[i];
+        dbknee4[i] = db_knee[i];
+    }
+    for (i = 0; i < 8; i++) { floor8[i] = floor_of[i]; fgain8[i] = (uint16_t)fast_gain(i); }
+    memcpy(freqs3, sample_rates, sizeof sample_rates);
+    memcpy(bitrate19, kbps_of, sizeof kbps_of);
 }
 
 /* ---------------- context ---------------- */
@@ -432,12 +469,12 @@ static int search_allocation(orc_ac3enc_t *s, int frame_bits)
     int b, ch, csnr, fsnr;
 
     s->sdecaycod = 2; s->fdecaycod = 1; s->sgaincod = 1; s->dbkneecod = 2; s->floorcod = 4; s->fgaincod = 4;
-    p.sdecay = (15 + 2 * s->sdecaycod) >> s->halfrate;             /* sdecaytab, ac3tab.h:145 */
-    p.fdecay = (63 + 20 * s->fdecaycod) >> s->halfrate;            /* fdecaytab :149 */
-    { static const int sg[4] = { 0x540, 0x4d8, 0x478, 0x410 }; p.sgain = sg[s->sgaincod]; }
-    { static const int dk[4] = { 0x000, 0x700, 0x900, 0xb00 }; p.dbknee = dk[s->dbkneecod]; }
-    { static const int fl[8] = { 0x2f0, 0x2b0, 0x270, 0x230, 0x1f0, 0x170, 0x0f0, 0xf800 }; p.floor = fl[s->floorcod]; }
-    p.fgain = 128 * (s->fgaincod + 1);                             /* fgaintab :161 */
+    p.sdecay = slow_decay(s->sdecaycod) >> s->halfrate;            /* sdecaytab, ac3tab.h:145 */
+    p.fdecay = fast_decay(s->fdecaycod) >> s->halfrate;            /* fdecaytab :149 */
+    p.sgain = slow_gain[s->sgaincod];
+    p.dbknee = db_knee[s->dbkneecod];
+    p.floor = floor_of[s->floorcod];
+    p.fgain = fast_gain(s->fgaincod);                              /* fgaintab :161 */
 
     /* fixed side information (ac3enc.cpp:880-916) */
     frame_bits += 65 + acmod_extra[s->acmod];
@@ -660,9 +697,7 @@ static unsigned gf_pow(unsigned a, unsigned n, unsigned poly)
 orc_ac3enc_t *orc_ac3enc_init(int freq, int bitrate, int channels, int *frame_bytes)
 {
     static const uint8_t acmod_of[6] = { 1, 2, 3, 6, 7, 7 };
-    static const uint16_t rates[3] = { 48000, 44100, 32000 };
-    static const uint16_t kbps[19] = { 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320,
-                                       384, 448, 512, 576, 640 };
+    const uint16_t *rates = sample_rates, *kbps = kbps_of;
     orc_ac3enc_t *s;
     int i, j, found = 0, ch;
 

@@ -86,6 +86,10 @@ void orc_ac3enc_get_misc(orc_ac3enc_t *s, uint8_t *exp_strategy /*[6][6]*/, int8
                          int *csnroffst, int *fsnroffst);
 void orc_ac3enc_tables(int16_t *costab64, int16_t *sintab64, int16_t *xcos128, int16_t *xsin128,
                        uint16_t *crc256);
+void orc_ac3enc_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *hth50x3, uint8_t *baptab64,
+                            uint8_t *bndsz50, uint16_t *sdecay4, uint16_t *fdecay4, uint16_t *sgain4,
+                            uint16_t *dbknee4, uint16_t *floor8, uint16_t *fgain8, uint16_t *freqs3,
+                            uint16_t *bitrate19);
 void orc_ac3enc_mdct512(int32_t *out256, const int16_t *in512);
 int orc_ac3enc_encode_frames(int freq, int bitrate, int channels, const int16_t *pcm, int n,
                              const uint8_t *chmap, uint8_t *out_or_null);

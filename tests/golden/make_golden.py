@@ -9,6 +9,9 @@ What is pinned and by what:
   downmix.npz    REAL a52_downmix_init / a52_downmix_coeff / a52_downmix / a52_upmix results
   encoder.npz    our encoder oracle's own output and stage dumps (regression pin only: PARITY UNPINNED
                  against ac3enc, see oracle/ac3enc_oracle.c)
+  ac3tab.npz     the REAL encoder's constant tables (src/ac3enc/ac3tab.h:3-171 compiled unmodified behind
+                 oracle/ref_ac3tab_glue.cpp): ac3_window, latab, hth, baptab, sdecaytab ... fgaintab, bndsz,
+                 ac3_freqs, ac3_bitratetab   (`make_golden.py --only ac3tab` regenerates just this file)
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 """
 import ctypes
@@ -51,7 +54,34 @@ def ref_decode_with_taps(frames, flags, level, bias):
     return pcm, exps, baps, lfsr, fl.value
 
 
+AC3TAB_NAMES = ("ac3_freqs", "ac3_bitratetab", "ac3_window", "latab", "hth", "baptab", "sdecaytab", "fdecaytab",
+                "sgaintab", "dbkneetab", "floortab", "fgaintab", "bndsz")
+
+
+def make_ac3tab():
+    path = os.path.join(ROOT, "oracle", "_ref", "ac3tab_ref.so")
+    assert os.path.exists(path), "oracle/_ref/ac3tab_ref.so missing: run `make -C oracle` in the build container"
+    T = ctypes.CDLL(path)
+    T.refglue_ac3tab.restype = ctypes.c_void_p
+    T.refglue_ac3tab.argtypes = [ctypes.c_char_p, H.ip, H.ip]
+    d = {}
+    for name in AC3TAB_NAMES:
+        n, eb = H.ci(), H.ci()
+        ptr = T.refglue_ac3tab(name.encode(), ctypes.byref(n), ctypes.byref(eb))
+        assert ptr and n.value > 0, name
+        signed = name == "ac3_window"                       # the only signed table (short); the rest are unsigned
+        dt = {1: np.uint8, 2: np.int16 if signed else np.uint16}[eb.value]
+        d[name] = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), (n.value,)).copy()
+    d["hth"] = d["hth"].reshape(50, 3)
+    np.savez_compressed(os.path.join(OUT, "ac3tab.npz"), **d)
+    print("ac3tab.npz", os.path.getsize(os.path.join(OUT, "ac3tab.npz")), {k: v.shape for k, v in d.items()})
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "ac3tab":
+        make_ac3tab()
+        return
+    make_ac3tab()
     assert H.have_ref(), "oracle/_ref/liba52_ref.so missing: run `make -C oracle` in the build container"
     R = H.ref()
     # ---- decode fixtures -------------------------------------------------

@@ -1,0 +1,37 @@
+"""CPU: `python bench.py --gpus N` without a launcher starts N ranks of itself (fresh child processes, parent only
+collects) - the N-rank rendezvous, barrier and reductions run here over gloo with world size 2, no GPU, no engine."""
+import json
+import os
+import subprocess
+import sys
+
+from tests import _harness as H
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    d = _run(["--gpus", "2", "--launch-check"])
+    assert d["launch_check"] and d["n_gpus"] == 2
+    assert d["streams_total"] == 2 * 65536           # SUM over ranks of the contiguous shards = the whole job
+    assert abs(d["max_time"] - 0.002) < 1e-12        # MAX over ranks
+
+
+def test_single_rank_needs_no_rendezvous():
+    d = _run(["--gpus", "1", "--launch-check"])
+    assert d["n_gpus"] == 1 and d["streams_total"] == 65536
+
+
+def test_under_an_external_launcher_nothing_is_spawned():
+    """With WORLD_SIZE in the environment (torch.distributed.run) the script is a rank, not a launcher."""
+    d = _run(["--gpus", "2", "--launch-check"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert d["n_gpus"] == 1

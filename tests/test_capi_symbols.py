@@ -19,6 +19,25 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_library_exports_nothing_else():
+    """a52dec-0.7.5-cvs/test/globals:15-22 rejects a liba52 whose dynamic symbol table holds anything but a52_*; this
+    library adds exactly the encoder's two C++-mangled entry points (src/ac3enc/ac3enc.h:6-7), MapTab / IsMMX
+    (src/AC3ACM.cpp:87-90) and the ac3mi_* extension ABI (csrc/exports.map).  Every export must also be declared."""
+    pkg = H.pkg()
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    allowed_extra = {"_Z15AC3_encode_initiii", "_Z16AC3_encode_framePhPsS_", "MapTab", "IsMMX"}
+    stray = [s for s in syms if not (s.startswith("a52_") or s.startswith("ac3mi_") or s in allowed_extra)]
+    assert not stray, stray
+    assert allowed_extra <= set(syms)
+    declared = set(pkg.declared_symbols()) | allowed_extra
+    undeclared = [s for s in syms if s not in declared]
+    assert not undeclared, undeclared
+    for name in ("a52_init", "a52_samples", "a52_syncinfo", "a52_frame", "a52_dynrng", "a52_block", "a52_free",
+                 "a52_imdct_512", "a52_imdct_256", "a52_imdct_init", "a52_downmix_init", "a52_downmix_coeff"):
+        assert name in syms, name
+
+
 def test_no_cpu_fallback_without_gpu():
     pkg = H.pkg()
     lib = pkg.load_library()
@@ -97,3 +116,23 @@ def test_headers_are_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(H.ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_secondary_liba52_exports_downmix_host_arithmetic():
+    """a52_downmix_init / a52_downmix_coeff: bit-identical floats against the fixture frozen from the real liba52."""
+    import numpy as np
+    lib = H.pkg().load_library()
+    lib.a52_downmix_init.argtypes = [H.ci, H.ci, H.fp, H.cf, H.cf]
+    lib.a52_downmix_coeff.argtypes = [H.fp, H.ci, H.ci, H.cf, H.cf, H.cf]
+    d = np.load(os.path.join(H.GOLDEN, "downmix.npz"), allow_pickle=False)
+    for (acmod, flags, clev, slev), (out, lvl), coeff in zip(d["cases"], d["init"], d["coeff"]):
+        lv = H.cf(1.0)
+        got = lib.a52_downmix_init(int(acmod), int(flags), ctypes.byref(lv), np.float32(clev), np.float32(slev))
+        assert got == int(out) and np.float32(lv.value) == np.float32(lvl)
+        g = np.zeros(5, np.float32)
+        mask = lib.a52_downmix_coeff(H.P(g, H.fp), int(acmod), int(out), lv.value, np.float32(clev), np.float32(slev))
+        n = H.NFCHANS[int(acmod)]
+        if (int(acmod), int(out)) == (1, 10):
+            n = 1
+        assert mask == int(coeff[5])
+        assert np.array_equal(g[:n].view(np.uint32), coeff[:n].astype(np.float32).view(np.uint32))

@@ -80,3 +80,35 @@ def test_s16_converter_batch(engine, flags):
     assert rc == 0
     engine.sync()
     assert np.array_equal(d_out.cpu().numpy(), want)
+
+
+def test_secondary_liba52_exports_imdct(engine):
+    """a52_imdct_512 / a52_imdct_256 (liba52/a52_internal.h:118-119) exported as one-plane launches: host pointers in and
+    out like liba52's, a long/short/long chain through one delay plane with non-zero bias; against the oracle (pinned to
+    the real liba52 by tests/golden/imdct.npz) and, where oracle/_ref travelled, against the real liba52 itself."""
+    import ctypes
+    lib = engine.lib
+    for f in (lib.a52_imdct_512, lib.a52_imdct_256):
+        f.argtypes = [H.fp, H.fp, H.cf]
+        f.restype = None
+    lib.a52_imdct_init.argtypes = [ctypes.c_uint32]
+    lib.a52_imdct_init(0)
+    L = H.orc()
+    R = H.ref() if H.have_ref() else None
+    rng = np.random.default_rng(17)
+    kinds = [0, 1, 1, 0, 1, 0, 0]
+    biases = [0.0, 384.0, 0.5, 0.0, -1.0, 384.0, 0.0]
+    d_gpu = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    d_gpu[128:] = 7.0                                     # dead half of the plane: must come back untouched
+    d_orc, d_ref = d_gpu.copy(), d_gpu.copy()
+    for k, bias in zip(kinds, biases):
+        x = (rng.standard_normal(256) * 0.1).astype(np.float32)
+        g, o, r = x.copy(), x.copy(), x.copy()
+        (lib.a52_imdct_256 if k else lib.a52_imdct_512)(H.P(g, H.fp), H.P(d_gpu, H.fp), bias)
+        (L.orc_imdct_256 if k else L.orc_imdct_512)(H.P(o, H.fp), H.P(d_orc, H.fp), bias)
+        assert H.rms(g.astype(np.float64) - o) <= (1e-6 if bias != 384.0 else 4e-5)
+        assert H.rms(d_gpu[:128].astype(np.float64) - d_orc[:128]) <= 1e-6
+        assert np.all(d_gpu[128:] == 7.0)
+        if R is not None:
+            (R.a52_imdct_256 if k else R.a52_imdct_512)(H.P(r, H.fp), H.P(d_ref, H.fp), bias)
+            assert H.rms(g.astype(np.float64) - r) <= (1e-6 if bias != 384.0 else 4e-5)

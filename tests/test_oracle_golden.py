@@ -163,3 +163,62 @@ def test_encoder_rejects_bad_parameters():
         h = L.orc_ac3enc_init(freq, br, ch, ctypes.byref(fb))
         assert h and fb.value == want, (freq, br, ch, fb.value)
         L.orc_ac3enc_free(h)
+
+
+# ---- encoder spec tables: pinned to the reference's own header ----------------------------------------------------
+# tests/golden/ac3tab.npz is frozen from src/ac3enc/ac3tab.h:3-171, compiled unmodified behind
+# oracle/ref_ac3tab_glue.cpp (oracle/Makefile, `make_golden.py --only ac3tab`).  Both the encoder oracle and the
+# engine must use exactly these numbers.  What stays PARITY UNPINNED is the code of ac3enc.cpp itself.
+
+_SPEC_ORDER = ("ac3_window", "latab", "hth", "baptab", "bndsz", "sdecaytab", "fdecaytab", "sgaintab", "dbkneetab",
+               "floortab", "fgaintab", "ac3_freqs", "ac3_bitratetab")
+
+
+def _spec_buffers():
+    return {"ac3_window": np.zeros(256, np.int16), "latab": np.zeros(256, np.uint8), "hth": np.zeros((50, 3), np.uint16),
+            "baptab": np.zeros(64, np.uint8), "bndsz": np.zeros(50, np.uint8), "sdecaytab": np.zeros(4, np.uint16),
+            "fdecaytab": np.zeros(4, np.uint16), "sgaintab": np.zeros(4, np.uint16), "dbkneetab": np.zeros(4, np.uint16),
+            "floortab": np.zeros(8, np.uint16), "fgaintab": np.zeros(8, np.uint16), "ac3_freqs": np.zeros(3, np.uint16),
+            "ac3_bitratetab": np.zeros(19, np.uint16)}
+
+
+def _check_spec_tables(got, who):
+    ref = _load("ac3tab.npz")
+    assert set(ref.files) == set(_SPEC_ORDER)
+    for name in _SPEC_ORDER:
+        want = ref[name].astype(np.int64)
+        if name == "latab":
+            # the reference pads latab to 260 entries with zeros (ac3tab.h:51-78); addresses are clamped to 255
+            assert want.shape == (260,) and not want[256:].any()
+            want = want[:256]
+        assert np.array_equal(got[name].astype(np.int64), want), "%s: %s differs from src/ac3enc/ac3tab.h" % (who, name)
+
+
+def test_encoder_oracle_spec_tables_equal_the_reference_header():
+    L = H.orc()
+    b = _spec_buffers()
+    L.orc_ac3enc_spec_tables.restype = None
+    L.orc_ac3enc_spec_tables.argtypes = [ctypes.c_void_p] * 13
+    L.orc_ac3enc_spec_tables(*(b[n].ctypes.data for n in _SPEC_ORDER))
+    _check_spec_tables(b, "oracle/ac3enc_oracle.c")
+
+
+def test_engine_spec_tables_equal_the_reference_header():
+    """ac3mi_encode_spec_tables returns the values the encoder kernels are built with (host call, no GPU needed)."""
+    lib = H.pkg().load_library()
+    b = _spec_buffers()
+    lib.ac3mi_encode_spec_tables.argtypes = [ctypes.c_void_p] * 13
+    assert lib.ac3mi_encode_spec_tables(*(b[n].ctypes.data for n in _SPEC_ORDER)) == 0
+    _check_spec_tables(b, "libac3mi.so")
+
+
+def test_engine_window_equals_oracle_window_and_decoder_tables_agree():
+    """The decoder's bit-allocation tables are the encoder's in liba52's sign convention (spec_tables.h): cross-check
+    the two forms against the same fixture (hth: 0xc00 - value; latab: negated) through the oracle's decoder, which is
+    itself pinned to the real liba52."""
+    ref = _load("ac3tab.npz")
+    lib = H.pkg().load_library()
+    win = np.zeros(256, np.int16)
+    lib.ac3mi_encode_tables.argtypes = [ctypes.c_void_p] * 5
+    assert lib.ac3mi_encode_tables(None, None, None, None, win.ctypes.data) == 0
+    assert np.array_equal(win, ref["ac3_window"])

@@ -21,6 +21,18 @@ def test_framesize_guessing_needs_no_gpu():
     assert S.framesize(S.ac3_format(2, 44100, 128, block_align=1)) == 2 * 278
     assert S.framesize(S.ac3_format(2, 32000, 640, block_align=4)) == 2 * 1920
     assert S.framesize(S.ac3_format(2, 48000, 100, block_align=1)) == 2 * 192          # 12500 B/s: nearest is 96 kbps
+    # 24 kHz and 12 kHz: (rate >> 6) & 3 == 3 selects the kbps column of the reference's table (AC3ACM.cpp:128-149,
+    # 445, 455, 472): by hand, 192 kbps (24000 B/s) -> 2 * 192, block_align 640 = 2 * 320 is accepted as is,
+    # 9000 B/s is nearest to 72 -> 64 or 80 kbps: |9000 - 8000| = |9000 - 10000|, the first (64) wins -> 128;
+    # above 81000 B/s the worst case 2 * 640
+    assert S.framesize(S.ac3_format(2, 24000, 192, block_align=1)) == 2 * 192
+    assert S.framesize(S.ac3_format(2, 12000, 96, block_align=640)) == 640
+    assert S.framesize(S.ac3_format(2, 24000, 72, block_align=1)) == 2 * 64
+    assert S.framesize(S.ac3_format(6, 12000, 700, block_align=0)) == 2 * 640
+    # the other half / quarter rates hash to columns 0..2 (22050, 11025 -> 0; 16000 -> 2; 8000 -> 1)
+    assert S.framesize(S.ac3_format(2, 22050, 128, block_align=1)) == 2 * 384
+    assert S.framesize(S.ac3_format(2, 16000, 128, block_align=1)) == 2 * 256
+    assert S.framesize(S.ac3_format(2, 8000, 128, block_align=1)) == 2 * 278
     assert S._lib().ac3mi_pool_create(None, 4) is None
 
 
