@@ -230,7 +230,7 @@ def ac3_crc_ok(frames):
     return int(np.count_nonzero(bad1 | (crc != 0)))
 
 
-def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
+def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5, checks=True):
     """Whole-path numbers for the other BASELINE configs on the same batch size (frames resident in HBM):
     configs[2] encode (s16 PCM -> frames), bitstream decode (frames -> float PCM, both kernels) and
     decode -> s16 -> re-encode (configs[4]'s per-GPU transcode step).  Each: frames/s of this rank's shard
@@ -343,12 +343,12 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5):
     res["transcode"]["frames_failing_crc"] = ac3_crc_ok(tc_host)
     res["encode"]["all_frames_ok"] = res["encode"]["frames_failing_crc"] == 0
     res["transcode"]["all_frames_ok"] = res["transcode"]["frames_failing_crc"] == 0 and res["transcode"]["all_frames_decoded_ok"]
-    if rank == 0:
+    if rank == 0 and checks:
         res["encode"]["bit_exact_vs_oracle"] = check_against_oracle(pkg, eng, dev, enc, dec, chmap, pcm)
     res["_frames"] = enc_host[:64].reshape(64, 1, fb).copy()      # for the CPU rates beside these legs (dropped from the line)
     if os.environ.get("AC3MI_BENCH_MILLION") == "1":
         res["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, frames)
-    if dist is None:           # host-side work on up to 16 threads: single-process runs only
+    if dist is None and checks:           # host-side work on up to 16 threads: single-process runs only
         res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
                    "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
@@ -527,6 +527,7 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary decode/encode/transcode timings")
+    ap.add_argument("--no-checks", action="store_true", help="skip the untimed oracle check and the stream-layer leg (profiling runs)")
     ap.add_argument("--launch-check", action="store_true", help="N-rank rendezvous and reductions only (gloo, no GPU)")
     args = ap.parse_args()
 
@@ -602,7 +603,7 @@ def main():
     # ---- secondary timings (not the headline): full frame decode, encode, transcode ----
     extra = None
     if not args.no_extra:
-        extra = secondary_timings(pkg, eng, dev, S, rank, dist, barrier)
+        extra = secondary_timings(pkg, eng, dev, S, rank, dist, barrier, checks=not args.no_checks)
 
     if rank == 0:
         total_frames = S * world * args.steps
