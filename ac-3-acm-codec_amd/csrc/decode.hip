@@ -19,365 +19,9 @@
 //    dequantisation through one table (L1-resident); planes go straight to HBM
 //
 // Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
-#include "ac3mi_internal.h"
-#include "a52_levels.h"
-#include "wave_ops.h"
+#include "decode_common.h"
 
 namespace ac3mi {
-
-constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dwords, conflict-free across rows
-// The LFE row holds 7 exponents (bit_allocate_wave's lowcomp stage looks at bins up to 64 of any row): kept short and
-// last; with the dequantiser table read through L1 the wavefront's LDS is 6.5 KB = 24 wavefronts per CU, what the
-// 80 VGPRs of __launch_bounds__(64, 6) allow (the kernel is latency-bound, occupancy pays).
-constexpr int LFE_ROW = 68;
-constexpr int ROWS = 6 * ROW + LFE_ROW;
-__device__ __forceinline__ int row_off(int slot) { return slot < 5 ? slot * ROW : slot == 6 ? 5 * ROW : 6 * ROW; }
-
-__device__ const uint8_t k_nfchans[11] = {2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2};
-__device__ const float k_clev[4] = {(float)AC3MI_G_3DB, (float)AC3MI_G_45DB, (float)AC3MI_G_6DB, (float)AC3MI_G_45DB};
-__device__ const float k_slev[4] = {(float)AC3MI_G_3DB, (float)AC3MI_G_6DB, 0.f, (float)AC3MI_G_6DB};
-__device__ const uint8_t k_cpl_bnd0[16] = {31, 35, 37, 39, 41, 42, 43, 44, 45, 45, 46, 46, 47, 47, 48, 48};
-__device__ const int k_remat_edge[5] = {13, 25, 37, 61, 253};
-__device__ const int k_slowgain[4] = {0x540, 0x4d8, 0x478, 0x410};
-__device__ const int k_dbpb[4] = {0xc00, 0x500, 0x300, 0x100};
-__device__ const int k_floors[8] = {0x910, 0x950, 0x990, 0x9d0, 0xa10, 0xa90, 0xb10, 0x1400};
-__device__ const uint16_t k_kbps[19] = {32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 576, 640};
-
-// channel slots: 0..4 = fbw, 5 = lfe, 6 = coupling channel
-struct DecLDS {
-    uint8_t exp[ROWS];                    // rows at row_off(slot)
-    int8_t bap[ROWS];
-    int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
-    float cplco[5][18];
-    uint8_t gcode[128];                   // open 3/5/11-level codes: rings of 32 / 32 / 64 (a step opens <= 22 / 22 / 32)
-    uint8_t cplbnd[20];                   // coupling sub-band -> band
-    int16_t seg_base[9];                  // mantissa stream segments
-    uint8_t seg_ch[8], seg_start[8];
-    int8_t la_neg[256];
-    uint16_t hth[50];
-    int8_t width[64];
-    uint8_t band_end[30];
-    uint8_t band_of_bin[256];
-    int16_t bmask[52];                    // per-band mask of the channel being allocated
-};
-
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// the staged frame: byte-swapped dwords in dynamic LDS, frame_bytes/4 (rounded up) + 4 zero words
-struct FrameBits {
-    const uint32_t *w;
-    uint32_t last;          // highest index a 2-dword read may start at
-};
-
-// n in 1..32: the n bits starting at bit `pos` (reads past the padding return the padding)
-__device__ __forceinline__ uint32_t peek(const FrameBits fr, uint32_t pos, int n)
-{
-    uint32_t w = pos >> 5;
-    w = w < fr.last ? w : fr.last;
-    const uint64_t v = ((uint64_t)fr.w[w] << 32) | fr.w[w + 1];
-    return (uint32_t)((v << (pos & 31)) >> (64 - n));
-}
-__device__ __forceinline__ int32_t speek(const FrameBits fr, uint32_t pos, int n)
-{
-    return ((int32_t)(peek(fr, pos, n) << (32 - n))) >> (32 - n);
-}
-
-struct Rd {                                   // wave-uniform serial reader
-    FrameBits fr;
-    uint32_t pos;
-    // 64-bit window of the bits at `wpos` (scalar registers): one LDS read per ~32 bits instead of one per field
-    uint32_t wpos;
-    uint64_t win;
-    int avail;
-    __device__ __forceinline__ void prime()
-    {
-        uint32_t w = pos >> 5;
-        w = w < fr.last ? w : fr.last;
-        const uint32_t hi = rfl(fr.w[w]), lo = rfl(fr.w[w + 1]);
-        win = (((uint64_t)hi << 32) | lo) << (pos & 31);
-        avail = 64 - (int)(pos & 31);
-        wpos = pos;
-    }
-    __device__ __forceinline__ uint32_t get(int n)
-    {
-        if (n == 0) return 0;
-        if (pos != wpos || avail < n) prime();
-        const uint32_t v = (uint32_t)(win >> (64 - n));
-        win <<= n;
-        avail -= n;
-        pos += n;
-        wpos = pos;
-        return v;
-    }
-    __device__ __forceinline__ int32_t sget(int n)
-    {
-        const uint32_t v = get(n);
-        return ((int32_t)(v << (32 - n))) >> (32 - n);
-    }
-};
-
-__device__ __forceinline__ float sf_of(int e) { return __int_as_float((127 - 15 - e) << 23); }   // 2^-(15+e)
-
-__device__ __forceinline__ int wave_incl_scan(int v, int) { return (int)wave_incl_scan_u32((uint32_t)v); }
-
-// stream-persistent decoder fields (wave-uniform)
-struct St {
-    int fscod, halfrate, acmod, lfeon, nf;
-    float clev, slev, level, bias_unused, dynrng;
-    int output, dynrnge;
-    int chincpl, phsflginu, cplstrtmant, cplendmant, ncplbnd, cplstrtbnd;
-    uint32_t cplbndstrc;
-    int rematflg;
-    int endmant[5];
-    int bai, csnroffst;
-    int cbai[7];            // per-slot fsnroffst<<3 | fgaincod
-    int deltbae[6];         // 0..4 fbw, 5 = cpl
-    int cplfleak, cplsleak;
-    uint32_t lfsr;
-};
-
-struct DecodeParams {
-    const uint8_t *frames;
-    float *coef;
-    uint8_t *blksw;
-    uint32_t *status;
-    uint16_t *lfsr_state;
-    uint8_t *tap_exp;       // optional [S][F][6][7][256]
-    int8_t *tap_bap;        // optional, same shape
-    const uint16_t *lfsr_seq;   // [65535] LFSR states in cycle order starting at 1
-    const uint16_t *lfsr_idx;   // [65536] position of a state in that cycle
-    const DecTables *tab;
-    int n_streams, frames_per_stream, frame_stride, frame_bytes;
-    int req_flags;
-    float level;
-    int dynrng_on;
-    int acmod, lfeon;       // expected coded configuration (frame 0 of the batch)
-    int n_in, nfchans;
-    const int32_t *slot;    // optional: stream s keeps its LFSR state in lfsr_state[slot[s]]
-    uint32_t *frame_draws;  // [S][F] dither draws of each frame (written by the counting pass)
-    const uint16_t *frame_lfsr;   // [S][F] LFSR state at the start of each frame (frame-parallel pass)
-};
-
-// ---------------------------------------------------------------------------
-// exponents: L52/parse.c:218-270.  ngrps groups of 7 bits at `pos`; returns 1 on a
-// reserved code or an exponent outside 0..24.
-__device__ int read_exponents(const FrameBits fr, uint32_t pos, int strategy, int ngrps, int absexp,
-                              uint8_t *dst, int lane)
-{
-    const int rep = 1 << (strategy - 1);
-    int carry = absexp, bad = 0;
-    for (int g0 = 0; g0 < ngrps; g0 += 64) {
-        const int g = g0 + lane;
-        int d0 = 0, d1 = 0, d2 = 0, ok = 1;
-        if (g < ngrps) {
-            const int code = (int)peek(fr, pos + 7 * g, 7);
-            ok = code < 125;
-            d0 = code / 25 - 2;
-            d1 = (code / 5) % 5 - 2;
-            d2 = code % 5 - 2;
-            if (!ok) d0 = d1 = d2 = 0;
-        }
-        const int incl = wave_incl_scan(d0 + d1 + d2, lane);
-        const int e0 = carry + incl - (d1 + d2), e1 = e0 + d1, e2 = e1 + d2;
-        if (g < ngrps) {
-            if (!ok || e0 < 0 || e0 > 24 || e1 < 0 || e1 > 24 || e2 < 0 || e2 > 24) bad = 1;
-            uint8_t *p = dst + 3 * g * rep;
-            for (int r = 0; r < rep; r++) {
-                p[r] = (uint8_t)e0;
-                p[rep + r] = (uint8_t)e1;
-                p[2 * rep + r] = (uint8_t)e2;
-            }
-        }
-        carry += __shfl(incl, 63, 64);
-    }
-    return __any(bad) ? 1 : 0;
-}
-
-// ---------------------------------------------------------------------------
-// bit allocation, one lane = one channel: L52/bit_allocate.c:124-265
-
-struct BaCtx {
-    int fdecay, fgain, sdecay, sgain, dbknee, floor, snroffset, halfrate, fast, slow;
-    const uint16_t *hth;
-    const int8_t *deltba;       // may be null
-};
-
-__device__ __forceinline__ void ba_leak(BaCtx &c, int psd)
-{
-    c.fast += c.fdecay;
-    if (c.fast > psd + c.fgain) c.fast = psd + c.fgain;
-    c.slow += c.sdecay;
-    if (c.slow > psd + c.sgain) c.slow = psd + c.sgain;
-}
-
-__device__ __forceinline__ int ba_mask(const BaCtx &c, int mask, int psd, int band)
-{
-    const int h = c.hth[band >> c.halfrate];
-    if (psd > c.dbknee) mask -= (psd - c.dbknee) >> 2;
-    if (mask > h) mask = h;
-    mask -= c.snroffset + 128 * (c.deltba ? c.deltba[band] : 0);
-    mask = (mask > 0) ? 0 : ((-mask) >> 5);
-    return mask - c.floor;
-}
-
-__device__ __forceinline__ int8_t ba_width(const int8_t *width, int a)
-{
-    return a <= -64 ? 16 : a >= 0 ? 0 : width[a + 63];
-}
-
-__device__ void bit_allocate_lane(const DecLDS &L, BaCtx c, int bndstart, int start, int end, const uint8_t *e,
-                                  int8_t *bap)
-{
-    int band = bndstart, bin = start, psd = 0, mask;
-    if (start == 0) {
-        int lowcomp = 0;
-        const int last = end - 1;
-        do {
-            if (band < last) {
-                if (e[band + 1] == e[band] - 2) lowcomp = 384;
-                else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
-            }
-            psd = 128 * e[band];
-            mask = ba_mask(c, psd + c.fgain + lowcomp, psd, band);
-            bap[band] = ba_width(L.width, mask + 4 * e[band]);
-            band++;
-        } while (band < 3 || (band < 7 && e[band] > e[band - 1]));
-        c.fast = psd + c.fgain;
-        c.slow = psd + c.sgain;
-        while (band < 7) {
-            if (band < last) {
-                if (e[band + 1] == e[band] - 2) lowcomp = 384;
-                else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
-            }
-            psd = 128 * e[band];
-            ba_leak(c, psd);
-            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
-            mask = ba_mask(c, mask, psd, band);
-            bap[band] = ba_width(L.width, mask + 4 * e[band]);
-            band++;
-        }
-        if (end == 7) return;
-        do {
-            if (e[band + 1] == e[band] - 2) lowcomp = 320;
-            else if (lowcomp && e[band + 1] > e[band]) lowcomp -= 64;
-            psd = 128 * e[band];
-            ba_leak(c, psd);
-            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
-            mask = ba_mask(c, mask, psd, band);
-            bap[band] = ba_width(L.width, mask + 4 * e[band]);
-            band++;
-        } while (band < 20);
-        while (lowcomp > 128) {
-            lowcomp -= 128;
-            psd = 128 * e[band];
-            ba_leak(c, psd);
-            mask = (c.fast + lowcomp < c.slow) ? c.fast + lowcomp : c.slow;
-            mask = ba_mask(c, mask, psd, band);
-            bap[band] = ba_width(L.width, mask + 4 * e[band]);
-            band++;
-        }
-        bin = band;
-    }
-    do {
-        const int first = bin;
-        const int stop = L.band_end[band - 20] < end ? L.band_end[band - 20] : end;
-        psd = 128 * e[bin++];
-        while (bin < stop) {
-            const int next = 128 * e[bin++], d = next - psd;
-            const int q = d >> 9;
-            if (q <= -2) psd = next;
-            else if (q == -1) { int a = (-d) >> 1; psd = next + L.la_neg[a > 255 ? 255 : a]; }
-            else if (q == 0) psd += L.la_neg[d >> 1];
-        }
-        ba_leak(c, psd);
-        mask = ba_mask(c, c.fast < c.slow ? c.fast : c.slow, psd, band);
-        band++;
-        for (bin = first; bin < stop; bin++) bap[bin] = ba_width(L.width, mask + 4 * e[bin]);
-    } while (bin < end);
-}
-
-// The same allocation for one channel with the whole wavefront (one lane per band, then per bin):
-//  * band PSDs: each of the <= 50 bands integrated by its own lane (<= 24 dependent log-adds)
-//  * lowcomp (bands 0..21 of a channel that starts at bin 0) is a reset-or-decrement automaton:
-//    value = max(0, R(last reset) - 64 * decrements since); bands 20/21 take 128 off while > 128
-//  * the fast / slow leaks are prefix minima of psd + gain - band * decay seeded at the last band
-//    of the first loop (bit_allocate.c:150-166), or at the coupling leak values
-__device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int start, int end, const uint8_t *e,
-                                  int8_t *bap, int lane)
-{
-    constexpr int INF = 0x3fffffff, NEG = -0x3fffffff;
-    const int b = lane;
-    // S1: band PSD
-    int lo = b < 21 ? b : (int)L.band_end[b < 50 ? b - 21 : 0];
-    int hi = b < 20 ? b + 1 : (int)L.band_end[b < 50 ? b - 20 : 0];
-    lo = lo > start ? lo : start;
-    hi = hi < end ? hi : end;
-    const int w = b < 50 ? hi - lo : 0;
-    const bool live = w > 0;
-    lo = live ? lo : start;
-    int psd = 128 * e[lo];
-    const int wmax = (int)wave_last((uint32_t)wave_incl_scan_max(w));
-    for (int j = 1; j < wmax; j++) {
-        const int next = 128 * e[j < w ? lo + j : lo];
-        const int d = next - psd, q = d >> 9;
-        int idx = q == -1 ? (-d) >> 1 : d >> 1;
-        idx = idx < 0 ? 0 : idx > 255 ? 255 : idx;
-        const int la = L.la_neg[idx];
-        const int nv = q <= -2 ? next : q == -1 ? next + la : q == 0 ? psd + la : psd;
-        psd = j < w ? nv : psd;
-    }
-    // S2: lowcomp and the extent of the first loop
-    int lc = 0, bA = 0;
-    if (start == 0) {
-        const int eb = e[b < 253 ? b : 0], eb1 = e[b < 252 ? b + 1 : 0], ebm = e[b > 0 && b < 254 ? b - 1 : 0];
-        const bool upd = b < 20 && (b >= 7 || b < end - 1);
-        const bool reset = upd && eb1 == eb - 2;
-        const int dec = upd && !reset && eb1 > eb ? 1 : 0;
-        const int D = (int)wave_incl_scan_u32((uint32_t)dec);
-        const int rix = wave_incl_scan_max(reset ? b : NEG);
-        const int Dr = __shfl(D, rix < 0 ? 0 : rix, 64);
-        if (rix >= 0) { lc = (rix < 7 ? 384 : 320) - 64 * (D - Dr); lc = lc < 0 ? 0 : lc; }
-        const int l19 = __builtin_amdgcn_readlane(lc, 19);
-        lc = b == 20 ? (l19 > 128 ? l19 - 128 : 0) : b == 21 ? (l19 > 256 ? l19 - 256 : 0) : b >= 22 ? 0 : lc;
-        const unsigned long long stopm = __ballot(b >= 3 && b < 7 && !(eb > ebm));
-        bA = stopm ? __builtin_ctzll(stopm) : 7;
-    }
-    // S3: leaks
-    const int seed = start == 0 ? bA - 1 : bndstart;
-    const bool in = live && b >= seed;
-    int fast = wave_incl_scan_min(in ? psd + c.fgain - b * c.fdecay : INF) + b * c.fdecay;
-    int slow = wave_incl_scan_min(in ? psd + c.sgain - b * c.sdecay : INF) + b * c.sdecay;
-    if (start != 0) {
-        const int ff = c.fast + (b - bndstart + 1) * c.fdecay, sl = c.slow + (b - bndstart + 1) * c.sdecay;
-        fast = ff < fast ? ff : fast;
-        slow = sl < slow ? sl : slow;
-    }
-    // S4: mask
-    int mask = (start == 0 && b < bA) ? psd + c.fgain + lc : (fast + lc < slow ? fast + lc : slow);
-    if (live) L.bmask[b] = (int16_t)ba_mask(c, mask, psd, b);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // S5: bins
-    const int shift = bndstart - (int)L.band_of_bin[start];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int bin = 64 * k + lane;
-        if (bin >= start && bin < end) bap[bin] = ba_width(L.width, (int)L.bmask[L.band_of_bin[bin] + shift] + 4 * e[bin]);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// mantissa helpers
-
-__device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t idx0, int k)
-{
-    // k-th draw (k = 0 first) = state after k+1 steps
-    uint32_t i = idx0 + (uint32_t)k + 1;
-    i %= 65535u;
-    const int16_t ns = (int16_t)P.lfsr_seq[i];
-    return (int16_t)((3 * ns) >> 2);
-}
 
 // ---------------------------------------------------------------------------
 
