@@ -98,6 +98,9 @@ struct DecodeLaunch {
     uint16_t *frame_lfsr;   // [S][F] workspace
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
+// decode_wg.hip: one workgroup per stream; X == nullptr: coefficient planes (+ taps) to HBM as launch_decode does;
+// else the transform is fused in (identity routing only: returns hipErrorInvalidValue for a mixing plan)
+hipError_t launch_decode_wg(const DeviceTables &tab, const DecodeLaunch &L, const XformLaunch *X, int grid_cap, hipStream_t stream);
 void build_dec_tables(DecTables *t, uint16_t *lfsr_seq /*[65535]*/, uint16_t *lfsr_idx /*[65536]*/);
 
 struct EncodeLaunch {

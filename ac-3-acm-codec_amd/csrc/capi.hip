@@ -416,6 +416,10 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->ws_tc_bytes = 0;
     ctx->slots = nullptr;
     ctx->decode_mode = 0;
+    if (const char *e = getenv("AC3MI_DECODE_MODE")) {          // test aid: default front-end variant (ac3mi_set_decode_mode)
+        const int m = atoi(e);
+        if (m >= 0 && m <= 3) ctx->decode_mode = m;
+    }
     ctx->tile_frames = 131072;
     ctx->no_overlap = getenv("AC3MI_NO_OVERLAP") != nullptr;     // profiling aid: one chunk, one stream, kernels back to back
     ctx->ws_draws = nullptr;
@@ -556,7 +560,7 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots)
 
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 2) return AC3MI_ERR_ARG;
+    if (!ctx || mode < 0 || mode > 3) return AC3MI_ERR_ARG;
     ctx->decode_mode = mode;
     return AC3MI_OK;
 }
@@ -584,6 +588,15 @@ static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_p
     if (frames_per_stream < 2) return false;
     if (ctx->decode_mode) return ctx->decode_mode == 2;
     return n_streams < 5120;
+}
+
+// one workgroup per stream (decode_wg.hip)?  auto: whenever the frame-parallel variant is not the better fit and there
+// are enough streams to give every CU a few workgroups; mode 3 forces it, modes 1 / 2 force the one-wavefront variants
+static bool use_wg_kernel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
+{
+    if (ctx->decode_mode) return ctx->decode_mode == 3;
+    if (use_frame_parallel(ctx, n_streams, frames_per_stream)) return false;
+    return n_streams >= 256;
 }
 
 static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)
@@ -719,7 +732,13 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         return AC3MI_ERR_ARG;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (const int g = taps ? 0 : tile_streams(ctx, n_streams, frames_per_stream)) {
+    bool identity = X.plan.n_in == X.plan.n_out;
+    for (int o = 0; o < X.plan.n_out && identity; o++)
+        for (int c = 0; c < X.plan.n_in; c++)
+            if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
+    const bool wgk = use_wg_kernel(ctx, n_streams, frames_per_stream);
+    const bool fused = wgk && identity && !taps;                 // no workspace at all: nothing to tile
+    if (const int g = (taps || fused) ? 0 : tile_streams(ctx, n_streams, frames_per_stream)) {
         // bounded workspace: whole streams at a time (streams are independent; state arrays move with them)
         const int32_t *slots0 = ctx->slots;
         int rc = AC3MI_OK;
@@ -738,16 +757,60 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     const size_t nfr = (size_t)n_streams * frames_per_stream;
     float *coef = taps && taps->d_coef ? taps->d_coef : nullptr;
     uint8_t *blksw = taps && taps->d_blksw ? taps->d_blksw : nullptr;
-    {
+    if (!fused) {
         int r = ensure_ws(ctx, coef ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float),
                           blksw ? 0 : nfr * 6 * X.plan.nfchans + 4);
         if (r != AC3MI_OK) return r;
+        if (!coef) coef = ctx->ws_coef;
+        if (!blksw) blksw = ctx->ws_blksw;
     }
-    if (!coef) coef = ctx->ws_coef;
-    if (!blksw) blksw = ctx->ws_blksw;
 
     const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
+    // Many independent streams: one workgroup per stream, one wavefront per channel, the transform fused in when every
+    // coded plane is an output plane (decode_wg.hip) - no coefficient planes in HBM.  Stage taps and mixing outputs
+    // take the same front end with the planes written out, then the transform kernel.
+    if (wgk) {
+        DecodeLaunch D;
+        D.frames = d_frames;
+        D.frame_bytes = desc->frame_bytes;
+        D.frame_stride = frame_stride;
+        D.n_streams = n_streams;
+        D.frames_per_stream = frames_per_stream;
+        D.req_flags = desc->flags;
+        D.acmod = desc->acmod;
+        D.lfeon = desc->lfeon ? 1 : 0;
+        D.dynrng_on = desc->dynrng ? 1 : 0;
+        D.level = desc->level;
+        D.coef = coef;
+        D.blksw = blksw;
+        D.status = d_status;
+        D.lfsr = d_lfsr;
+        D.slot = ctx->slots;
+        D.tap_exp = taps && taps->d_exp ? taps->d_exp : nullptr;
+        D.tap_bap = taps && taps->d_bap ? taps->d_bap : nullptr;
+        D.frame_parallel = 0;
+        D.frame_draws = nullptr;
+        D.frame_lfsr = nullptr;
+        X.coef = coef;
+        X.blksw = blksw;
+        X.delay = d_delay;
+        X.slot = ctx->slots;
+        X.delay_stride = 6 * 128;
+        X.pcm = d_pcm;
+        X.pcm16 = d_pcm16;
+        X.s16_flags = out_flags;
+        X.n_streams = n_streams;
+        X.frames = frames_per_stream;
+        X.bias = desc->bias;
+        if (fused) {
+            HIPCHK(ctx, launch_decode_wg(ctx->tab, D, &X, 0, ctx->stream));
+            return AC3MI_OK;
+        }
+        HIPCHK(ctx, launch_decode_wg(ctx->tab, D, nullptr, 0, ctx->stream));
+        HIPCHK(ctx, launch_xform(ctx->tab, X, ctx->stream));
+        return AC3MI_OK;
+    }
     // A large batch goes through in two chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
     const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 5.06 / 4.93 / 4.94 / 5.04 ms (4 was best before the front end ran 6 waves/SIMD)
@@ -1044,9 +1107,14 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     }
     const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
+    bool identity = X.plan.n_in == X.plan.n_out;
+    for (int o = 0; o < X.plan.n_out && identity; o++)
+        for (int c = 0; c < X.plan.n_in; c++)
+            if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
+    const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
@@ -1072,6 +1140,21 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         D.frame_parallel = fp ? 1 : 0;
         D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
         D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;
+        if (fused) {
+            XformLaunch Y = X;
+            Y.coef = nullptr;
+            Y.blksw = nullptr;
+            Y.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * n_out * 128;
+            Y.slot = D.slot;
+            Y.delay_stride = 6 * 128;
+            Y.pcm = nullptr;
+            Y.pcm16 = ws_s16 + f0 * 1536 * n_out;
+            Y.s16_flags = out_flags;
+            Y.n_streams = ns;
+            Y.frames = frames_per_stream;
+            Y.bias = 384.0f;
+            return launch_decode_wg(ctx->tab, D, &Y, 0, ctx->stream);
+        }
         return launch_decode(ctx->tab, D, ctx->stream);
     };
     auto middle = [&](int k, hipStream_t st) -> hipError_t {
@@ -1118,7 +1201,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     };
     if (n_chunks == 1) {
         HIPCHK(ctx, front(0));
-        HIPCHK(ctx, middle(0, ctx->stream));
+        if (!fused) HIPCHK(ctx, middle(0, ctx->stream));
         HIPCHK(ctx, back(0));
         return AC3MI_OK;
     }

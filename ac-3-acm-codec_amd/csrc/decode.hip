@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                             c.floor = fl >> 5;
                             c.fast = fl0;
                             c.slow = sl0;
-                            bit_allocate_wave(L, c, bndstart, start, end, L.exp + row_off(slot), L.bap + row_off(slot), lane);
+                            bit_allocate_wave(L, L.bmask, c, bndstart, start, end, L.exp + row_off(slot), L.bap + row_off(slot), lane);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

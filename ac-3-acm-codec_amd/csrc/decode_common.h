@@ -285,7 +285,8 @@ __device__ void bit_allocate_lane(const DecLDS &L, BaCtx c, int bndstart, int st
 //    value = max(0, R(last reset) - 64 * decrements since); bands 20/21 take 128 off while > 128
 //  * the fast / slow leaks are prefix minima of psd + gain - band * decay seeded at the last band
 //    of the first loop (bit_allocate.c:150-166), or at the coupling leak values
-__device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int start, int end, const uint8_t *e,
+template <class LDS>
+__device__ void bit_allocate_wave(const LDS &L, int16_t *bmask, const BaCtx &c, int bndstart, int start, int end, const uint8_t *e,
                                   int8_t *bap, int lane)
 {
     constexpr int INF = 0x3fffffff, NEG = -0x3fffffff;
@@ -337,7 +338,7 @@ __device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int s
     }
     // S4: mask
     int mask = (start == 0 && b < bA) ? psd + c.fgain + lc : (fast + lc < slow ? fast + lc : slow);
-    if (live) L.bmask[b] = (int16_t)ba_mask(c, mask, psd, b);
+    if (live) bmask[b] = (int16_t)ba_mask(c, mask, psd, b);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -346,13 +347,20 @@ __device__ void bit_allocate_wave(DecLDS &L, const BaCtx &c, int bndstart, int s
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int bin = 64 * k + lane;
-        if (bin >= start && bin < end) bap[bin] = ba_width(L.width, (int)L.bmask[L.band_of_bin[bin] + shift] + 4 * e[bin]);
+        if (bin >= start && bin < end) bap[bin] = ba_width(L.width, (int)bmask[L.band_of_bin[bin] + shift] + 4 * e[bin]);
     }
 }
 
 // ---------------------------------------------------------------------------
 // mantissa helpers
 
+__device__ __forceinline__ int16_t dither_at(const uint16_t *lfsr_seq, uint32_t idx0, int k)
+{
+    uint32_t i = idx0 + (uint32_t)k + 1;
+    i %= 65535u;
+    const int16_t ns = (int16_t)lfsr_seq[i];
+    return (int16_t)((3 * ns) >> 2);
+}
 __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t idx0, int k)
 {
     // k-th draw (k = 0 first) = state after k+1 steps

@@ -166,17 +166,35 @@ __device__ __forceinline__ cf tw_at(const float2 *tw, int k) { float2 t = tw[k];
 
 // Long block.  xa[n1] = X[2m], xb[n1] = X[255-2m], m = 8*n1 + l8.  tw = this lane's
 // 16 merged twiddles.  Accumulates into ft.
+// The two halves of a transform (the fused decoder, decode_wg.hip, puts a workgroup barrier between them):
+// first half = pre-twiddle, DFT-16, lane twiddles, 8x16 transpose; common to the long and the short block.
 template <typename TW>
-__device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&xb)[16], const TW &tw,
-                                           float2 *ex, int l8, FirstTail &ft)
+__device__ __forceinline__ void imdct_first_half(const float (&xa)[16], const float (&xb)[16], const TW &tw,
+                                                 float2 *ex, int l8, cf (&r)[16])
 {
-    cf v[16], r[16];
+    cf v[16];
 #pragma unroll
     for (int n = 0; n < 16; n++) v[n] = cmul(cf{xa[n], xb[n]}, C32_RE[n], C32_IM[n]);
     dft16(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw_at(tw, k));
     transpose_8x16(ex, l8, v, r);
+}
+
+__device__ __forceinline__ void imdct_long_second_half(cf (&r)[16], FirstTail &ft);
+__device__ __forceinline__ void imdct_short_second_half(cf (&r)[16], FirstTail &ft);
+
+template <typename TW>
+__device__ __forceinline__ void imdct_long(const float (&xa)[16], const float (&xb)[16], const TW &tw,
+                                           float2 *ex, int l8, FirstTail &ft)
+{
+    cf r[16];
+    imdct_first_half(xa, xb, tw, ex, l8, r);
+    imdct_long_second_half(r, ft);
+}
+
+__device__ __forceinline__ void imdct_long_second_half(cf (&r)[16], FirstTail &ft)
+{
     dft8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
     dft8(r[8], r[9], r[10], r[11], r[12], r[13], r[14], r[15]);
 #pragma unroll
@@ -204,13 +222,13 @@ template <typename TW>
 __device__ __forceinline__ void imdct_short(const float (&xa)[16], const float (&xb)[16], const TW &tw,
                                             float2 *ex, int l8, FirstTail &ft)
 {
-    cf v[16], r[16];
-#pragma unroll
-    for (int n = 0; n < 16; n++) v[n] = cmul(cf{xa[n], xb[n]}, C32_RE[n], C32_IM[n]);
-    dft16(v);
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw_at(tw, k));
-    transpose_8x16(ex, l8, v, r);
+    cf r[16];
+    imdct_first_half(xa, xb, tw, ex, l8, r);
+    imdct_short_second_half(r, ft);
+}
+
+__device__ __forceinline__ void imdct_short_second_half(cf (&r)[16], FirstTail &ft)
+{
     dft4(r[0], r[1], r[2], r[3]);       // Y1[l8+16 k2]
     dft4(r[4], r[5], r[6], r[7]);       // Y2[l8+16 k2]
     dft4(r[8], r[9], r[10], r[11]);     // Y1[15-l8+16 k2]

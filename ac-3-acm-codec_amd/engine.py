@@ -215,7 +215,8 @@ class Engine:
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))
 
     def set_decode_mode(self, mode):
-        """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame (ac3mi_set_decode_mode)."""
+        """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame, 3 = one workgroup per stream
+        with the transform fused in (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
     def transcode_batch(self, dec, enc, frames, delay, lfsr, chmap, last, csnroffst, out=None, status=None, wait_torch=True):
