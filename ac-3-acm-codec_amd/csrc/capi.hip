@@ -590,13 +590,15 @@ static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_p
     return n_streams < 5120;
 }
 
-// one workgroup per stream (decode_wg.hip)?  auto: whenever the frame-parallel variant is not the better fit and there
-// are enough streams to give every CU a few workgroups; mode 3 forces it, modes 1 / 2 force the one-wavefront variants
+// one workgroup per stream (decode_wg.hip)?  Its eight wavefronts cut the latency of a frame to a third (64 - 256 one-frame
+// streams: 0.09 ms against 0.24 ms) and nothing but the frame and the PCM touches HBM, but a workgroup's wavefronts wait for
+// each other at the block's barriers, so the chip holds fewer busy wavefronts than with one wavefront per stream: measured
+// on one-frame streams it is ahead up to about 2 000 streams (1 024: 0.20 against 0.26 ms; 4 096: 0.57 against 0.40 ms;
+// 65 536: 8.8 against 4.4 ms).  auto: batches of up to 2 048 streams of at most four frames; mode 3 forces it.
 static bool use_wg_kernel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
     if (ctx->decode_mode) return ctx->decode_mode == 3;
-    if (use_frame_parallel(ctx, n_streams, frames_per_stream)) return false;
-    return n_streams >= 256;
+    return n_streams <= 2048 && frames_per_stream <= 4;
 }
 
 static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)
@@ -765,9 +767,9 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         if (!blksw) blksw = ctx->ws_blksw;
     }
 
-    const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
+    const bool fp = !wgk && use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
-    // Many independent streams: one workgroup per stream, one wavefront per channel, the transform fused in when every
+    // One workgroup per stream, one wavefront per channel, the transform fused in when every
     // coded plane is an output plane (decode_wg.hip) - no coefficient planes in HBM.  Stage taps and mixing outputs
     // take the same front end with the planes written out, then the transform kernel.
     if (wgk) {
@@ -1105,13 +1107,13 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         HIPCHK(ctx, hipMalloc(&ctx->ws_enc, need));
         ctx->ws_enc_bytes = need;
     }
-    const bool fp = use_frame_parallel(ctx, n_streams, frames_per_stream);
-    if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     bool identity = X.plan.n_in == X.plan.n_out;
     for (int o = 0; o < X.plan.n_out && identity; o++)
         for (int c = 0; c < X.plan.n_in; c++)
             if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
     const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
+    const bool fp = !fused && use_frame_parallel(ctx, n_streams, frames_per_stream);
+    if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
     const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms

@@ -29,13 +29,11 @@
 // runs beside both.  Coefficients live in LDS for one block period; HBM sees the frame once and the PCM once.
 //
 // Built with -ffp-contract=off: dequantised coefficients are bit-identical to liba52's; the transform arithmetic is
-// xform_core.h's (same operations as xform.hip).
+// xform_core.h's with its fused multiply-adds written out: the same bits as xform.hip produces from the same planes.
 #include "decode_common.h"
-// the transform's arithmetic may contract to FMA like xform.hip (1e-6 RMS tolerance); everything else in this file is
-// built with -ffp-contract=off (bit-identical coefficients)
-#pragma clang fp contract(fast)
+#include <stdio.h>
+#include <stdlib.h>
 #include "xform_core.h"
-#pragma clang fp contract(off)
 
 namespace ac3mi {
 
@@ -43,7 +41,8 @@ namespace wg {
 
 constexpr int N_WAVES = 8;
 #ifndef WG_LB
-#define WG_LB 4                             // waves per SIMD the register budget is set for (512-thread blocks: 2 per block)
+#define WG_LB 6                             // waves per SIMD the register budget is set for (512-thread blocks: 2 per block):
+                                            // 80 VGPRs, three workgroups per CU; measured 4 / 6 / 8: 10.3 / 8.8 / 11.7 ms per 65 536 frames
 #endif
 constexpr int W_LFE = 5, W_PARSE = 6, W_XFORM = 7;
 constexpr int PLANE = 272;                  // plane pitch in floats: 8-lane groups of the transformer hit different banks
@@ -78,7 +77,8 @@ struct WgLDS {
     uint8_t band_of_bin[256];
     int16_t bmask[6][52];                   // bit_allocate_wave scratch, one per channel wave
     float qtab[760];
-    uint8_t gcode[3][GC];
+    uint8_t gcode[3 * GC + 4];              // open codes by kind and group; the last bytes are a sink for lanes that open nothing
+    uint32_t desc[128];                     // per row byte: dequantiser base | members per code << 10 | opener bits << 12 | coded << 15
     uint32_t cnt[7][2];                     // census per slot: [0] plain bits | n3 << 16 | n5 << 24, [1] n11 | zeros << 8
     int exp_err;                            // a channel wave found a reserved exponent code / an exponent outside 0..24
     int blkswm_hist[6];
@@ -100,6 +100,14 @@ __device__ __forceinline__ int16_t to_s16(float v)
     return (int16_t)i;
 }
 
+// Measurement aid (make EXTRA=-DWG_STAMPS, a separate library): wave w of workgroup 0 records s_memtime at fixed points of
+// the first frame of its SECOND stream (warm caches) into a buffer nothing else reads; dumped by launch_decode_wg.
+#ifdef WG_STAMPS
+#define STAMP(id) do { if (W.stamps && blockIdx.x == 0 && s == (int)gridDim.x && f == 0 && lane == 0) W.stamps[wave * 64 + (id)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
+
 __device__ __forceinline__ void wg_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -110,6 +118,9 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// An opaque copy of a lane-dependent value: address arithmetic derived from it stays where it is used instead of being
+// hoisted out of the (long) block loop and spilled.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int ldsu(const int &v) { return (int)rfl((uint32_t)v); }           // wave-uniform LDS word
 __device__ __forceinline__ float ldsf(const float &v) { return __uint_as_float(rfl(__float_as_uint(v))); }
 
@@ -124,61 +135,134 @@ struct WgParams {
     float bias;
     int n_out;
     int8_t wslot[6];            // OUT 2: plane o -> WAVE slot
+    unsigned long long *stamps; // WG_STAMPS builds only: [8 waves][64] s_memtime values of one workgroup's second stream
 };
 
-// parser-private values that travel from the first to the second half of a block's side information
-struct ParseCarry {
-    int cplexpstr, lfeexpstr, chexp, redo;
+// The parser's bit reader: the 64 frame words from the current position on sit one per lane in a VGPR; a field is two
+// v_readlane (scalar index) and a funnel shift - no LDS round trip per field.  The window is reloaded when the position
+// leaves it (after the exponent payloads are skipped).  Wave-uniform like Rd.
+struct VRd {
+    const uint32_t *w;
+    uint32_t last;          // as FrameBits::last (words up to last + 1 exist)
+    uint32_t pos, base;
+    uint32_t vwin;
+    int lane;
+    __device__ __forceinline__ void load()
+    {
+        base = pos >> 5;
+        uint32_t i = base + (uint32_t)lane;
+        i = i < last + 1u ? i : last + 1u;
+        vwin = w[i];
+    }
+    __device__ __forceinline__ uint32_t get(int n)
+    {
+        if (n == 0) return 0;
+        uint32_t wi = (pos >> 5) - base;
+        if (wi >= 63u) { load(); wi = 0; }
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)vwin, (int)wi);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vwin, (int)wi + 1);
+        const uint32_t v = (uint32_t)(((((uint64_t)hi << 32) | lo) << (pos & 31u)) >> (64 - n));
+        pos += (uint32_t)n;
+        return v;
+    }
+    __device__ __forceinline__ int32_t sget(int n)
+    {
+        const uint32_t v = get(n);
+        return ((int32_t)(v << (32 - n))) >> (32 - n);
+    }
 };
+__device__ __forceinline__ VRd make_reader(const FrameBits FB, uint32_t pos, int lane)
+{
+    VRd rd{FB.w, FB.last, pos, 0, 0, lane};
+    rd.load();
+    return rd;
+}
+
+// The parser's view of the stream (a52_state_t's side-information fields, L52/a52_internal.h:35-88) lives in LDS, one copy
+// per workgroup, touched by the parser wavefront only: every lane reads the same word (ldsu), lane 0 writes.  Nothing of
+// it occupies registers across the workgroup barriers.
+struct ParserState {
+    int fscod, halfrate, acmod, lfeon, nf;
+    float clev, slev, level, dynrng;
+    int output, dynrnge;
+    int chincpl, phsflginu, cplstrtmant, cplendmant, ncplbnd, cplstrtbnd;
+    uint32_t cplbndstrc;
+    int rematflg;
+    int endmant[5];
+    int bai, csnroffst, cbai[7], deltbae[6], cplfleak, cplsleak;
+    uint32_t pos;               // the bit reader's position
+    int cplexpstr, lfeexpstr, chexp, redo;      // from the first to the second half of a block's side information
+    uint32_t status, reuse0;
+    int frame_dead;
+    uint32_t lfsr_idx;          // position in the dither generator's cycle
+    int lfsr_live;
+    int hth_fscod;
+};
+
+#define PSET(field, value) do { const auto pset_v_ = (value); if (lane == 0) (field) = pset_v_; } while (0)
 
 // ---- side information, first half: L52/parse.c:572-736 without the exponent payloads (their positions are recorded) ----
-__device__ void parse_block_a(Rd &rd, St &st, BlkInfo &B, const BlkInfo &prev, ParseCarry &pc, int blk, uint32_t &reuse0, int lane)
+#ifdef WG_STAMPS
+#define PSTAMP(i) do { if (dbg && lane == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+__device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, const BlkInfo &prev, int blk, int lane, unsigned long long *dbg = nullptr)
 {
-    const int nf = st.nf;
-    int err = 0, blkswm = 0, dithmask = 0;
-    pc.cplexpstr = pc.lfeexpstr = pc.chexp = pc.redo = 0;
-    // coupling coordinates and band structure persist from block to block (and frame to frame)
+    PSTAMP(0);
+    VRd rd = make_reader(FB, (uint32_t)ldsu((const int &)S.pos), lane);
+    const int nf = ldsu(S.nf), acmod = ldsu(S.acmod), lfeon = ldsu(S.lfeon);
+    int err = 0, blkswm = 0, dithmask = 0, reuse0 = 0;
+    int cplexpstr = 0, lfeexpstr = 0, chexp = 0, redo = 0;
+    // coupling coordinates persist from block to block (and frame to frame)
     for (int i = lane; i < 90; i += 64) (&B.cplco[0][0])[i] = (&prev.cplco[0][0])[i];
+    PSTAMP(1);
     do {
         for (int i = 0; i < nf; i++) blkswm |= rd.get(1) << i;
         for (int i = 0; i < nf; i++) dithmask |= rd.get(1) << i;
-        int twice = !st.acmod;
+        int twice = !acmod;
         do {
             if (rd.get(1)) {
                 const int code = rd.sget(8);
-                if (st.dynrnge) {
+                if (ldsu(S.dynrnge)) {
                     const float range = (float)(((code & 0x1f) | 0x20) << 13) * sf_of(3 - (code >> 5));
-                    st.dynrng = st.level * range;
+                    PSET(S.dynrng, ldsf(S.level) * range);
                 }
             }
         } while (twice--);
 
+        PSTAMP(2);
+        int chincpl = ldsu(S.chincpl);
         if (rd.get(1)) {                                            // cplstre
-            st.chincpl = 0;
+            chincpl = 0;
             if (rd.get(1)) {                                        // cplinu
-                for (int i = 0; i < nf; i++) st.chincpl |= rd.get(1) << i;
-                if (st.acmod < 2) { err = 1; break; }
-                if (st.acmod == 2) st.phsflginu = rd.get(1);
+                for (int i = 0; i < nf; i++) chincpl |= rd.get(1) << i;
+                PSET(S.chincpl, chincpl);
+                if (acmod < 2) { err = 1; break; }
+                if (acmod == 2) PSET(S.phsflginu, (int)rd.get(1));
                 const int begf = rd.get(4), endf = rd.get(4);
                 if (endf + 3 - begf < 0) { err = 1; break; }
                 const int nsub = endf + 3 - begf;
-                st.ncplbnd = nsub;
-                st.cplstrtbnd = k_cpl_bnd0[begf];
-                st.cplstrtmant = begf * 12 + 37;
-                st.cplendmant = endf * 12 + 73;
-                st.cplbndstrc = 0;
+                int ncplbnd = nsub;
+                uint32_t strc = 0;
                 for (int i = 0; i < nsub - 1; i++)
-                    if (rd.get(1)) { st.cplbndstrc |= 1u << i; st.ncplbnd--; }
-            }
+                    if (rd.get(1)) { strc |= 1u << i; ncplbnd--; }
+                PSET(S.ncplbnd, ncplbnd);
+                PSET(S.cplstrtbnd, (int)k_cpl_bnd0[begf]);
+                PSET(S.cplstrtmant, begf * 12 + 37);
+                PSET(S.cplendmant, endf * 12 + 73);
+                PSET(S.cplbndstrc, strc);
+            } else PSET(S.chincpl, 0);
         } else if (blk == 0) reuse0 = 1;
-        if (st.chincpl) {                                           // coupling coordinates
+        if (chincpl) {                                              // coupling coordinates
+            const int ncplbnd = ldsu(S.ncplbnd);
             int any = 0;
             for (int i = 0; i < nf; i++)
-                if ((st.chincpl >> i) & 1) {
+                if ((chincpl >> i) & 1) {
                     if (rd.get(1)) {
                         const int master = 3 * rd.get(2);
                         any = 1;
-                        for (int j = 0; j < st.ncplbnd; j++) {
+                        for (int j = 0; j < ncplbnd; j++) {
                             const int ex = rd.get(4);
                             int ma = rd.get(4);
                             ma = (ex == 15) ? (ma << 14) : ((ma | 0x10) << 13);
@@ -187,53 +271,51 @@ __device__ void parse_block_a(Rd &rd, St &st, BlkInfo &B, const BlkInfo &prev, P
                         }
                     } else if (blk == 0) reuse0 = 1;
                 }
-            wave_sync();
-            if (st.acmod == 2 && st.phsflginu && any)
-                for (int j = 0; j < st.ncplbnd; j++)
+            if (acmod == 2 && ldsu(S.phsflginu) && any)
+                for (int j = 0; j < ncplbnd; j++)
                     if (rd.get(1) && lane == 0) B.cplco[1][j] = -B.cplco[1][j];
         }
-        if (st.acmod == 2) {
+        if (acmod == 2) {
             if (rd.get(1)) {                                        // rematstr
-                const int end = st.chincpl ? st.cplstrtmant : 253;
-                int i = 0;
-                st.rematflg = 0;
-                do st.rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                const int end = chincpl ? ldsu(S.cplstrtmant) : 253;
+                int i = 0, flg = 0;
+                do flg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                PSET(S.rematflg, flg);
             } else if (blk == 0) reuse0 = 1;
         }
-        int cplexpstr = 0, lfeexpstr = 0, chexp = 0;
-        if (st.chincpl) cplexpstr = rd.get(2);
+        PSTAMP(3);
+        if (chincpl) cplexpstr = rd.get(2);
         for (int i = 0; i < nf; i++) chexp |= rd.get(2) << (2 * i);
-        if (st.lfeon) lfeexpstr = rd.get(1);
+        if (lfeon) lfeexpstr = rd.get(1);
         if (blk == 0) {
-            if (st.chincpl && !cplexpstr) reuse0 = 1;
-            if (st.lfeon && !lfeexpstr) reuse0 = 1;
+            if (chincpl && !cplexpstr) reuse0 = 1;
+            if (lfeon && !lfeexpstr) reuse0 = 1;
             for (int i = 0; i < nf; i++) if (!((chexp >> (2 * i)) & 3)) reuse0 = 1;
         }
-#pragma unroll
-        for (int i = 0; i < 5; i++)
-            if (i < nf && !err && ((chexp >> (2 * i)) & 3)) {
-                if ((st.chincpl >> i) & 1) st.endmant[i] = st.cplstrtmant;
+        const int cplstrtmant = ldsu(S.cplstrtmant), cplendmant = ldsu(S.cplendmant);
+        for (int i = 0; i < nf; i++)
+            if (!err && ((chexp >> (2 * i)) & 3)) {
+                if ((chincpl >> i) & 1) PSET(S.endmant[i], cplstrtmant);
                 else {
                     const int bw = rd.get(6);
                     if (bw > 60) err = 1;
-                    else st.endmant[i] = bw * 3 + 73;
+                    else PSET(S.endmant[i], bw * 3 + 73);
                 }
             }
+        PSTAMP(4);
         if (err) break;
         // exponent fields: recorded, not read (the channel waves decode them side by side)
-        int redo = 0;
         if (cplexpstr) {
-            const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
+            const int ngrp = (cplendmant - cplstrtmant) / (3 << (cplexpstr - 1));
             const int e0 = rd.get(4) << 1;
             redo = 64;
             if (lane == 0) { B.absexp[6] = e0; B.exp_pos[6] = (int)rd.pos; B.ngrp[6] = ngrp; }
             rd.pos += 7 * ngrp;
         }
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
+        for (int i = 0; i < nf; i++) {
             const int es = (chexp >> (2 * i)) & 3;
-            if (i < nf && es) {
-                const int gs = 3 << (es - 1), ngrp = (st.endmant[i] + gs - 4) / gs;
+            if (es) {
+                const int gs = 3 << (es - 1), ngrp = (ldsu(S.endmant[i]) + gs - 4) / gs;
                 redo |= 1 << i;
                 const int e0 = rd.get(4);
                 if (lane == 0) { B.absexp[i] = e0; B.exp_pos[i] = (int)rd.pos; B.ngrp[i] = ngrp; }
@@ -247,62 +329,62 @@ __device__ void parse_block_a(Rd &rd, St &st, BlkInfo &B, const BlkInfo &prev, P
             if (lane == 0) { B.absexp[5] = e0; B.exp_pos[5] = (int)rd.pos; B.ngrp[5] = 2; }
             rd.pos += 14;
         }
-        pc.cplexpstr = cplexpstr;
-        pc.lfeexpstr = lfeexpstr;
-        pc.chexp = chexp;
-        pc.redo = redo;
     } while (0);
+    PSTAMP(5);
     if (lane == 0) {
         B.err = err;
         B.blkswm = blkswm;
         B.dithmask = dithmask;
-#pragma unroll
-        for (int i = 0; i < 5; i++) B.expstr[i] = (pc.chexp >> (2 * i)) & 3;
-        B.expstr[5] = pc.lfeexpstr;
-        B.expstr[6] = pc.cplexpstr;
+        for (int i = 0; i < 5; i++) B.expstr[i] = (chexp >> (2 * i)) & 3;
+        B.expstr[5] = lfeexpstr;
+        B.expstr[6] = cplexpstr;
+        S.pos = rd.pos;
+        S.cplexpstr = cplexpstr;
+        S.lfeexpstr = lfeexpstr;
+        S.chexp = chexp;
+        S.redo = redo;
+        if (reuse0) S.reuse0 = 1;
     }
     // sub-band -> band of the coupling channel (parse.c:448-456): one lane per sub-band
     if (lane < 18) {
-        const uint32_t below = st.cplbndstrc & ((1u << lane) - 1u);
+        const uint32_t below = (uint32_t)ldsu((const int &)S.cplbndstrc) & ((1u << lane) - 1u);
         B.cplbnd[lane] = (uint8_t)(lane - __popc(below));
     }
+    PSTAMP(6);
 }
 
 // ---- second half: bit-allocation parameters, delta bit allocation, skip field (parse.c:738-772, 800-804) ----
-__device__ void parse_block_b(Rd &rd, St &st, BlkInfo &B, WgLDS &L, ParseCarry &pc, int blk, uint32_t &reuse0, int lane)
+__device__ void parse_block_b(const FrameBits FB, ParserState &S, BlkInfo &B, int8_t (*deltba)[52], int blk, int lane)
 {
-    const int nf = st.nf;
-    int err = ldsu(B.err), redo = pc.redo;
+    VRd rd = make_reader(FB, (uint32_t)ldsu((const int &)S.pos), lane);
+    const int nf = ldsu(S.nf), lfeon = ldsu(S.lfeon), chincpl = ldsu(S.chincpl), acmod = ldsu(S.acmod);
+    int err = ldsu(B.err), redo = ldsu(S.redo), reuse0 = 0;
     if (!err) do {
-        if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
+        if (rd.get(1)) { redo = 127; PSET(S.bai, (int)rd.get(11)); }
         else if (blk == 0) reuse0 = 1;
         if (rd.get(1)) {
             redo = 127;
-            st.csnroffst = rd.get(6);
-            if (st.chincpl) st.cbai[6] = rd.get(7);
-#pragma unroll
-            for (int i = 0; i < 5; i++) if (i < nf) st.cbai[i] = rd.get(7);
-            if (st.lfeon) st.cbai[5] = rd.get(7);
+            PSET(S.csnroffst, (int)rd.get(6));
+            if (chincpl) PSET(S.cbai[6], (int)rd.get(7));
+            for (int i = 0; i < nf; i++) PSET(S.cbai[i], (int)rd.get(7));
+            if (lfeon) PSET(S.cbai[5], (int)rd.get(7));
         } else if (blk == 0) reuse0 = 1;
-        if (st.chincpl) {
+        if (chincpl) {
             if (rd.get(1)) {
                 redo |= 64;
-                st.cplfleak = 9 - rd.get(3);
-                st.cplsleak = 9 - rd.get(3);
+                PSET(S.cplfleak, 9 - (int)rd.get(3));
+                PSET(S.cplsleak, 9 - (int)rd.get(3));
             } else if (blk == 0) reuse0 = 1;
         }
         if (rd.get(1)) {                                            // deltbaie
             redo = 127;
-            if (st.chincpl) st.deltbae[5] = rd.get(2);
-#pragma unroll
-            for (int i = 0; i < 5; i++) if (i < nf) st.deltbae[i] = rd.get(2);
-#pragma unroll
-            for (int pass = 0; pass < 6; pass++) {
+            if (chincpl) PSET(S.deltbae[5], (int)rd.get(2));
+            for (int i = 0; i < nf; i++) PSET(S.deltbae[i], (int)rd.get(2));
+            for (int pass = 0; pass <= nf && !err; pass++) {
                 const int slot = pass == 0 ? 5 : pass - 1;          // cpl first, then fbw (parse.c:763-771)
-                if (err || pass > nf) continue;
-                if (slot == 5 && !st.chincpl) continue;
-                if (st.deltbae[slot] != 1) continue;
-                if (lane < 50) L.deltba[slot][lane] = 0;            // parse_deltba: parse.c:272-294
+                if (slot == 5 && !chincpl) continue;
+                if (ldsu(S.deltbae[slot]) != 1) continue;
+                if (lane < 50) deltba[slot][lane] = 0;              // parse_deltba: parse.c:272-294
                 int nseg = rd.get(3), band = 0;
                 do {
                     band += rd.get(5);
@@ -310,7 +392,7 @@ __device__ void parse_block_b(Rd &rd, St &st, BlkInfo &B, WgLDS &L, ParseCarry &
                     d -= (d >= 4) ? 3 : 4;
                     if (!len) continue;
                     if (band + len >= 50) { err = 1; break; }
-                    if (lane < len) L.deltba[slot][band + lane] = (int8_t)d;
+                    if (lane < len) deltba[slot][band + lane] = (int8_t)d;
                     band += len;
                 } while (nseg--);
             }
@@ -321,38 +403,108 @@ __device__ void parse_block_b(Rd &rd, St &st, BlkInfo &B, WgLDS &L, ParseCarry &
             rd.pos += 8 * n;
         }
     } while (0);
-    bool allzero = !st.csnroffst && !(st.chincpl && (st.cbai[6] >> 3)) && !(st.lfeon && (st.cbai[5] >> 3));
-#pragma unroll
-    for (int i = 0; i < 5; i++)
-        if (i < nf && (st.cbai[i] >> 3)) allzero = false;
+    wave_sync();
+    // publish what the channel waves and the transformer need (one field per lane where it is a plain copy)
+    const int csnroffst = ldsu(S.csnroffst);
+    bool allzero = !csnroffst && !(chincpl && (ldsu(S.cbai[6]) >> 3)) && !(lfeon && (ldsu(S.cbai[5]) >> 3));
+    for (int i = 0; i < nf; i++)
+        if (ldsu(S.cbai[i]) >> 3) allzero = false;
     float gain[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!err) a52_downmix_coeff_hd(gain, st.acmod, st.output, st.dynrng, st.clev, st.slev);     // parse.c:810-811
+    const int output = ldsu(S.output);
+    const float dynrng = ldsf(S.dynrng);
+    if (!err) a52_downmix_coeff_hd(gain, acmod, output, dynrng, ldsf(S.clev), ldsf(S.slev));      // parse.c:810-811
+    if (lane < 5) { B.endmant[lane] = S.endmant[lane]; }
+    if (lane < 7) B.cbai[lane] = S.cbai[lane];
+    if (lane < 6) B.deltbae[lane] = S.deltbae[lane];
     if (lane == 0) {
+        const int e0 = S.endmant[0], e1 = S.endmant[1], rematflg = acmod == 2 ? S.rematflg : 0;
         B.err = err;
-        B.halfrate = st.halfrate;
+        B.halfrate = S.halfrate;
         B.mant_pos = (int)rd.pos;
-        B.chincpl = st.chincpl;
-        B.cplstrtmant = st.cplstrtmant;
-        B.cplendmant = st.cplendmant;
-        B.cplstrtbnd = st.cplstrtbnd;
-        B.rematflg = st.acmod == 2 ? st.rematflg : 0;
-        B.remat_end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
-        B.need_fix = (st.chincpl || (st.acmod == 2 && st.rematflg)) ? 1 : 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { B.endmant[i] = st.endmant[i]; B.gain[i] = gain[i]; }
+        B.chincpl = chincpl;
+        B.cplstrtmant = S.cplstrtmant;
+        B.cplendmant = S.cplendmant;
+        B.cplstrtbnd = S.cplstrtbnd;
+        B.rematflg = rematflg;
+        B.remat_end = e0 < e1 ? e0 : e1;
+        B.need_fix = (chincpl || rematflg) ? 1 : 0;
+        B.gain[0] = gain[0]; B.gain[1] = gain[1]; B.gain[2] = gain[2]; B.gain[3] = gain[3]; B.gain[4] = gain[4];
         B.redo = redo;
         B.allzero = allzero ? 1 : 0;
-        B.bai = st.bai;
-        B.csnroffst = st.csnroffst;
-#pragma unroll
-        for (int i = 0; i < 7; i++) B.cbai[i] = st.cbai[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) B.deltbae[i] = st.deltbae[i];
-        B.cplfleak = st.cplfleak;
-        B.cplsleak = st.cplsleak;
-        B.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+        B.bai = S.bai;
+        B.csnroffst = csnroffst;
+        B.cplfleak = S.cplfleak;
+        B.cplsleak = S.cplsleak;
+        B.lfe_gain = (output & AC3MI_LFE) ? dynrng : 0.f;
+        S.pos = rd.pos;
+        if (reuse0) S.reuse0 = 1;
     }
 }
+
+// ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205): frame header and BSI; returns false for a frame the
+// batch cannot hold (no sync word, other channel configuration, too long, an output liba52 would refuse) ----
+__device__ bool parse_frame_header(const FrameBits FB, const uint32_t *frw, ParserState &S, uint16_t *hth, const DecodeParams &P, int lane)
+{
+    const uint32_t w0 = rfl(frw[0]), w1 = rfl(frw[1]);
+    const int b4 = (w1 >> 24) & 0xff, b5 = (w1 >> 16) & 0xff, b6 = (w1 >> 8) & 0xff;
+    if ((w0 >> 16) != 0x0b77) return false;
+    if (b5 >= 0x60) return false;
+    if ((b4 & 63) >= 38 || (b4 & 0xc0) == 0xc0) return false;
+    const int fscod = b4 >> 6, bsid = b5 >> 3, acmod0 = b6 >> 5;
+    PSET(S.fscod, fscod);
+    PSET(S.halfrate, bsid < 9 ? 0 : bsid - 8);
+    PSET(S.acmod, acmod0);
+    if (acmod0 != P.acmod) return false;
+    {
+        const int code = b4 & 63, rate = k_kbps[code >> 1];
+        const int fbytes = fscod == 0 ? 4 * rate : fscod == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
+        if (fbytes > P.frame_bytes) return false;                // frame_bytes = the largest frame of the batch (44.1 kHz alternates)
+    }
+    VRd rd = make_reader(FB, 6 * 8 + 3, lane);
+    int acmod = acmod0;
+    if (acmod == 2 && rd.get(2) == 2) acmod = 10;                 // dsurmod -> DOLBY
+    float clev = 0.f, slev = 0.f;
+    if ((acmod & 1) && acmod != 1) clev = k_clev[rd.get(2)];
+    if (acmod & 4) slev = k_slev[rd.get(2)];
+    PSET(S.clev, clev);
+    PSET(S.slev, slev);
+    const int lfeon = rd.get(1);
+    PSET(S.lfeon, lfeon);
+    if (lfeon != P.lfeon) return false;
+    float level = P.level;
+    int output = a52_downmix_init_hd(acmod, P.req_flags, &level, clev, slev);
+    if (output < 0) return false;
+    if (lfeon && (P.req_flags & AC3MI_LFE)) output |= AC3MI_LFE;
+    PSET(S.output, output);
+    PSET(S.level, level * 2);
+    PSET(S.dynrng, level * 2);
+    PSET(S.dynrnge, P.dynrng_on);
+    if (lane < 6) S.deltbae[lane] = 2;
+    int twice = !acmod;
+    do {
+        rd.get(5);
+        if (rd.get(1)) rd.get(8);
+        if (rd.get(1)) rd.get(8);
+        if (rd.get(1)) rd.get(7);
+    } while (twice--);
+    rd.get(2);
+    if (rd.get(1)) rd.get(14);
+    if (rd.get(1)) rd.get(14);
+    if (rd.get(1)) {
+        int len = rd.get(6);
+        do rd.get(8); while (len--);
+    }
+    PSET(S.nf, (int)k_nfchans[acmod0]);
+    if (ldsu(S.hth_fscod) != fscod) {
+        if (lane < 50) hth[lane] = P.tab->hth[fscod][lane];
+        PSET(S.hth_fscod, fscod);
+    }
+    PSET(S.pos, rd.pos);
+    PSET(S.status, (uint32_t)output << 16);
+    return true;
+}
+
+
 
 // ---- T1 of one slot: exponents, bit allocation, census --------------------------------------------------------------
 __device__ void slot_t1(WgLDS &L, const BlkInfo &B, const FrameBits FB, int slot, int wave, int lane)
@@ -403,26 +555,30 @@ __device__ void slot_t1(WgLDS &L, const BlkInfo &B, const FrameBits FB, int slot
     wave_sync();
 }
 
+// Row bytes (L.bap): 0 = no bits, 3..16 = that many plain bits, 32 / 64 / 96 = member of a 3- / 5- / 11-level code
+// (ba_width's -1 / -2 / -3, remapped when the width table is staged), so that  plain bits = b & 31,  kind = b >> 5.
+// Everything below is branch-free: four bins per lane, the per-code constants come from L.desc.
+
 // census of a slot's mantissas (also run when nothing was re-allocated: the coupling range may have moved)
-__device__ void slot_census(WgLDS &L, int slot, int start, int end, int lane)
+__device__ __forceinline__ void slot_census(WgLDS &L, int slot, int start, int end, int lane)
 {
     const int8_t *brow = L.bap + row_off(slot);
-    uint32_t a = 0, b = 0;
-    if (slot != 5 || lane < LFE_ROW / 4) {
-        const uint32_t bap4 = *reinterpret_cast<const uint32_t *>(brow + 4 * lane);
+    const bool have = slot != 5 || lane < LFE_ROW / 4;
+    const uint32_t bap4 = have ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
+    uint32_t a = 0, z = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int bin = 4 * lane + j;
-            const int w = (int)(int8_t)(bap4 >> (8 * j));
-            if (bin >= start && bin < end) {
-                a += w > 0 ? (uint32_t)w : w == -1 ? 1u << 16 : w == -2 ? 1u << 24 : 0u;
-                b += w == -3 ? 1u : w == 0 ? 1u << 8 : 0u;
-            }
-        }
+    for (int j = 0; j < 4; j++) {
+        const int bin = 4 * lane + j;
+        const uint32_t act = (uint32_t)(bin >= start) & (uint32_t)(bin < end);
+        const uint32_t b = ((bap4 >> (8 * j)) & 0xffu) * act;
+        const uint32_t k1 = b >> 5;
+        a += (b & 31u) | (((1u << (8 * k1)) >> 8) << 16);         // plain bits | n3 << 16 | n5 << 24 | (n11: carried in z)
+        z += (k1 == 3u ? 1u : 0u) | ((act & (uint32_t)(b == 0u)) << 8);
     }
+    // (1 << 8 k1) >> 8 puts an 11-level member at bit 32: dropped above, counted in z instead
     a = wave_sum_u32(a);
-    b = wave_sum_u32(b);
-    if (lane == 0) { L.cnt[slot][0] = a; L.cnt[slot][1] = b; }
+    z = wave_sum_u32(z);
+    if (lane == 0) { L.cnt[slot][0] = a; L.cnt[slot][1] = z; }
 }
 
 // where a slot's mantissas start: prefix over the segments of the block in bitstream order (parse.c:813-879: channel 0,
@@ -489,8 +645,8 @@ __device__ SegBase segment_prefix(const WgLDS &L, const BlkInfo &B, int slot, in
 // registers a channel wave keeps from T2a to T2b for its 4 bins
 struct BinRegs {
     uint32_t raw[4];
-    uint32_t bap4, exp4;
-    int gm[4];              // group | member << 16 | kind << 20 (kind 3 = not a grouped code)
+    uint32_t bap4, exp4;    // row bytes (inactive bins zeroed) and exponents
+    uint32_t gm[4];         // group | member << 12
     int cd;                 // draw index of the lane's first zero-bit bin
 };
 
@@ -500,83 +656,82 @@ __device__ __forceinline__ void slot_t2a(WgLDS &L, const FrameBits FB, const uin
     const uint8_t *erow = L.exp + row_off(slot);
     const int8_t *brow = L.bap + row_off(slot);
     const bool have = slot != 5 || lane < LFE_ROW / 4;
-    R.bap4 = have ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
+    uint32_t bap4 = have ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
     R.exp4 = have ? *reinterpret_cast<const uint32_t *>(erow + 4 * lane) : 0u;
-    int w[4], kind[4];
+    uint32_t b[4], d[4], inc[4], zero[4];
     uint32_t gl = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int bin = 4 * lane + j;
-        const bool act = bin >= start && bin < end;
-        w[j] = act ? (int)(int8_t)(R.bap4 >> (8 * j)) : -9;
-        kind[j] = w[j] == -1 ? 0 : w[j] == -2 ? 1 : w[j] == -3 ? 2 : 3;
-        gl += kind[j] < 3 ? 1u << (10 * kind[j]) : 0u;
+        const uint32_t act = (uint32_t)(bin >= start) & (uint32_t)(bin < end);
+        b[j] = ((bap4 >> (8 * j)) & 0xffu) * act;
+        zero[j] = act & (uint32_t)(b[j] == 0u);
+        d[j] = L.desc[b[j]];
+        inc[j] = (1u << (30u - 10u * (b[j] >> 5))) & 0x3fffffffu;      // 1 in the 10-bit field of the bin's kind (3-level: bits 20-29, 5-level: 10-19, 11-level: 0-9), 0 for plain bins
+        gl += inc[j];
     }
-    const uint32_t gin = wave_incl_scan_u32(gl), gex = gin - gl;
-    int c3 = sb.r3 + (int)(gex & 0x3ffu), c5 = sb.r5 + (int)((gex >> 10) & 0x3ffu), c11 = sb.r11 + (int)(gex >> 20);
-    int nb[4];
+    R.bap4 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    const uint32_t gex = wave_incl_scan_u32(gl) - gl;
+    // phase of each kind at the start of the segment and the group its first member belongs to
+    const int q3 = (int)(((uint32_t)sb.r3 * 0xaaabu) >> 17), q5 = (int)(((uint32_t)sb.r5 * 0xaaabu) >> 17), q11 = sb.r11 >> 1;
+    uint32_t run = gex + ((uint32_t)(sb.r3 - 3 * q3) << 20) + ((uint32_t)(sb.r5 - 3 * q5) << 10) + (uint32_t)(sb.r11 & 1);
+    uint32_t nb[4];
     uint32_t nbsum = 0, ndsum = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        int rank = 0;
-        if (kind[j] == 0) rank = c3++;
-        else if (kind[j] == 1) rank = c5++;
-        else if (kind[j] == 2) rank = c11++;
-        const int per = kind[j] == 2 ? 2 : 3;
-        const int grp = kind[j] == 2 ? rank >> 1 : (int)(((uint32_t)rank * 0xaaabu) >> 17);       // rank / 3, rank < 2^15
-        const int mem = rank - grp * per;
-        const bool opens = kind[j] < 3 && mem == 0;
-        nb[j] = w[j] > 0 ? w[j] : opens ? (kind[j] == 0 ? 5 : 7) : 0;
-        R.gm[j] = grp | (mem << 16) | (kind[j] << 20);
-        nbsum += (uint32_t)nb[j];
-        ndsum += w[j] == 0 ? (uint32_t)sb.mult : 0u;
+        const uint32_t k1 = b[j] >> 5;
+        const uint32_t x = (run >> (30u - 10u * k1)) & 0x3ffu;        // phase + rank inside the segment (0 for plain bins: bits 30, 31)
+        const uint32_t two = (uint32_t)(k1 == 3u);
+        const uint32_t q = two ? x >> 1 : (x * 171u) >> 9;            // x / members per code, x < 256 + 3
+        const uint32_t mem = x - q * (3u - two);
+        const uint32_t opens = (uint32_t)(k1 != 0u) & (uint32_t)(mem == 0u);
+        nb[j] = (b[j] & 31u) + opens * ((d[j] >> 12) & 7u);
+        const uint32_t gbase = k1 == 1u ? (uint32_t)q3 : k1 == 2u ? (uint32_t)q5 : (uint32_t)q11;
+        R.gm[j] = (gbase + q) | (mem << 12);
+        run += inc[j];
+        nbsum += nb[j];
+        ndsum += zero[j] * (uint32_t)sb.mult;
+        // the opener publishes its code where the other members will look for it; everybody else writes to the sink
+        zero[j] = opens ? (k1 - 1u) * GC + (R.gm[j] & 0xfffu) : 3u * GC;      // (zero[] reused: gcode slot)
     }
     const uint32_t bl = nbsum | (ndsum << 16);
     const uint32_t bin_ = wave_incl_scan_u32(bl);
     const uint32_t off = sb.bit + (bin_ & 0xffffu) - nbsum;
     R.cd = sb.draw + (int)(bin_ >> 16) - (int)ndsum;
-    // the lane's fields sit in at most 79 consecutive bits: four dwords of the frame
+    // the lane's fields are at most 64 consecutive bits starting at `off`: a 64-bit window out of three dwords
     uint32_t wi = off >> 5;
     wi = wi < FB.last ? wi : FB.last;
-    const uint32_t d0 = frw[wi], d1 = frw[wi + 1], d2 = frw[wi + 2], d3 = frw[wi + 3];
-    uint32_t r = off & 31u;
+    const uint32_t d0 = frw[wi], d1 = frw[wi + 1], d2 = frw[wi + 2];
+    const uint32_t k = off & 31u;
+    uint64_t win = ((((uint64_t)d0 << 32) | d1) << k) | (uint64_t)((d2 >> 1) >> (31u - k));
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t sel = r >> 5;
-        const uint32_t hi = sel == 0 ? d0 : sel == 1 ? d1 : d2, lo = sel == 0 ? d1 : sel == 1 ? d2 : d3;
-        const uint64_t v = (((uint64_t)hi << 32) | lo) << (r & 31u);
-        R.raw[j] = nb[j] ? (uint32_t)(v >> 32) >> (32 - nb[j]) : 0u;
-        const int k = (R.gm[j] >> 20) & 3;
-        if (k < 3 && ((R.gm[j] >> 16) & 15) == 0) L.gcode[k][R.gm[j] & 0xffff] = (uint8_t)R.raw[j];
-        r += (uint32_t)nb[j];
+        R.raw[j] = ((uint32_t)(win >> 32) >> 1) >> (31u - nb[j]);       // top nb bits (0 for nb = 0)
+        win <<= nb[j];
+        L.gcode[zero[j]] = (uint8_t)R.raw[j];
     }
 }
 
-// dequantised value of bin j (before the exponent / gain scale); coupling-channel and zero-bit handling is the caller's
-__device__ __forceinline__ float bin_q(const WgLDS &L, const BinRegs &R, int j, int w)
+// dequantised value of bin j before the exponent / gain scale (0 for a zero-bit bin)
+__device__ __forceinline__ float bin_q(const WgLDS &L, const BinRegs &R, int j)
 {
-    const int k = (R.gm[j] >> 20) & 3, mem = (R.gm[j] >> 16) & 15, grp = R.gm[j] & 0xffff;
-    const bool coded = k < 3 || w == 3 || w == 4;
-    const int code = k < 3 ? (int)L.gcode[k][grp] : (int)R.raw[j];
-    const int per = k == 2 ? 2 : 3;
-    const int base = k == 0 ? 0 : k == 1 ? 96 : k == 2 ? 480 : w == 3 ? 736 : 744;
-    const int ti = base + code * (k < 3 ? per : 1) + (k < 3 ? mem : 0);
-    const float tv = L.qtab[coded ? ti : 0];
-    const float pv = (float)((((int32_t)(R.raw[j] << ((32 - w) & 31))) >> ((32 - w) & 31)) * (1 << ((16 - w) & 31)));
-    return coded ? tv : w > 0 ? pv : 0.f;
+    const uint32_t b = (R.bap4 >> (8 * j)) & 0xffu, k1 = b >> 5, nbp = b & 31u;
+    const uint32_t d = L.desc[b];
+    const uint32_t grp = R.gm[j] & 0xfffu, mem = R.gm[j] >> 12;
+    const uint32_t code = L.gcode[k1 ? (k1 - 1u) * GC + grp : 3u * GC];
+    const uint32_t coded = (d >> 15) & 1u;
+    const uint32_t qi = (d & 0x3ffu) + (k1 ? code * ((d >> 10) & 3u) + mem : R.raw[j]);
+    const float tv = L.qtab[coded ? qi : 0u];
+    const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
+    return coded ? tv : pv;
 }
 
-}  // namespace wg
+// ---- the transformer: one block of all output planes per pass, 8 lanes per plane (xform_core.h arithmetic, as xform.hip).
+// Nothing stays in registers between its three parts: the transposed points and the first/tail values wait in the
+// transformer's own LDS scratch (L.ex), so the parts can sit in different phases of the workgroup's schedule.
 
-using namespace wg;
-
-namespace wg {
-
-#pragma clang fp contract(fast)
-// ---- the transformer's three parts for one block (xform_core.h arithmetic, as xform.hip) ----------------------------
-
-// part A: coefficient plane (LDS) -> registers, first half of the transform.  Identity routing: output o = input plane o.
-__device__ __forceinline__ void xform_part_a(WgLDS &L, int o, int sw, int l8, float2 *ex, cf (&r)[16])
+// part A: coefficient plane (LDS) -> registers, pre-twiddle, DFT-16, lane twiddles, rows of the 8x16 transpose
+__device__ __forceinline__ void xform_part_a(const WgLDS &L, int o, int sw, int l8, float2 *ex)
 {
     const float *plane = L.planes + o * PLANE;
     float xa[16], xb[16];
@@ -584,26 +739,60 @@ __device__ __forceinline__ void xform_part_a(WgLDS &L, int o, int sw, int l8, fl
 #pragma unroll
         for (int n = 0; n < 16; n++) {
             const int m = 8 * n + l8;
-            xa[n] = plane[2 * m];
-            xb[n] = plane[255 - 2 * m];
+            xa[n] = __builtin_fmaf(1.f, plane[2 * m], 0.f);         // as xform.hip's load_long with one plane of weight +1
+            xb[n] = __builtin_fmaf(1.f, plane[255 - 2 * m], 0.f);
         }
-        imdct_first_half(xa, xb, L.twl + l8 * 16, ex, l8, r);
+        imdct_first_half_put(xa, xb, L.twl + l8 * 16, ex, l8);
     } else {
         const int f = l8 >> 2, n2 = l8 & 3;
 #pragma unroll
         for (int n = 0; n < 16; n++) {
-            xa[n] = plane[16 * n + 4 * n2 + f];
-            xb[n] = plane[254 + f - 16 * n - 4 * n2];
+            xa[n] = __builtin_fmaf(1.f, plane[16 * n + 4 * n2 + f], 0.f);
+            xb[n] = __builtin_fmaf(1.f, plane[254 + f - 16 * n - 4 * n2], 0.f);
         }
-        imdct_first_half(xa, xb, L.tws + l8 * 16, ex, l8, r);
+        imdct_first_half_put(xa, xb, L.tws + l8 * 16, ex, l8);
     }
 }
 
+constexpr int FT_PITCH = 36;                // floats per lane of the parked first/tail values (32 + pad)
+
+// part B: columns of the transpose, second half of the transform, first/tail values parked in the scratch
+__device__ __forceinline__ void xform_part_b(int sw, int l8, float2 *ex)
+{
+    cf r[16];
+    transpose_8x16_get(ex, l8, r);
+    FirstTail ft = FirstTail{};
+    if (!sw) imdct_long_second_half(r, ft);
+    else imdct_short_second_half(r, ft);
+    wave_sync();                                                // every lane of the group has read its columns
+    float4 *park = reinterpret_cast<float4 *>(reinterpret_cast<float *>(ex) + l8 * FT_PITCH);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        park[k] = make_float4(ft.f0[4 * k], ft.f0[4 * k + 1], ft.f0[4 * k + 2], ft.f0[4 * k + 3]);
+        park[2 + k] = make_float4(ft.f1[4 * k], ft.f1[4 * k + 1], ft.f1[4 * k + 2], ft.f1[4 * k + 3]);
+        park[4 + k] = make_float4(ft.t0[4 * k], ft.t0[4 * k + 1], ft.t0[4 * k + 2], ft.t0[4 * k + 3]);
+        park[6 + k] = make_float4(ft.t1[4 * k], ft.t1[4 * k + 1], ft.t1[4 * k + 2], ft.t1[4 * k + 3]);
+    }
+}
+
+// part C: window + overlap-add + bias, new tails, PCM out
 template <int OUT>
-__device__ __forceinline__ void xform_part_c(WgLDS &L, const WgParams &W, const FirstTail &ft, int o, int l8, int lane, bool store,
+__device__ __forceinline__ void xform_part_c(WgLDS &L, const WgParams &W, int o, int l8, int lane, bool store, float2 *ex,
                                              size_t blk_index /* fidx * 6 + blk */)
 {
     const int n_out = W.n_out;
+    l8 = opaque(l8);
+    o = opaque(o);
+    float v[32];
+    {
+        const float4 *park = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(ex) + l8 * FT_PITCH);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 q = park[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+    }
+    wave_sync();                                                // the scratch becomes the s16 tile of this block
     float *dl = L.dly[o];
     int16_t *tile = reinterpret_cast<int16_t *>(L.ex);
     int wsl = 0;
@@ -617,10 +806,7 @@ __device__ __forceinline__ void xform_part_c(WgLDS &L, const WgParams &W, const 
         const float2 whi = *reinterpret_cast<const float2 *>(&L.win[254 - 2 * i]);
         const float2 d = *reinterpret_cast<const float2 *>(&dl[2 * i]);
         float2 lo, hi;
-        lo.x = ft.f0[j] * wlo.x + (d.x * whi.y + W.bias);
-        lo.y = ft.f1[j] * wlo.y + (d.y * whi.x + W.bias);
-        hi.x = d.y * wlo.y + W.bias - ft.f1[j] * whi.x;
-        hi.y = d.x * wlo.x + W.bias - ft.f0[j] * whi.y;
+        window_pair(v[j], v[8 + j], d, wlo, whi, W.bias, lo, hi);
         if (store) {
             if (OUT == 1) {
                 *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
@@ -631,12 +817,12 @@ __device__ __forceinline__ void xform_part_c(WgLDS &L, const WgParams &W, const 
                 tile[wsl + (254 - 2 * i) * n_out] = to_s16(hi.x);
                 tile[wsl + (255 - 2 * i) * n_out] = to_s16(hi.y);
             }
-            *reinterpret_cast<float2 *>(&dl[2 * i]) = make_float2(ft.t0[j], ft.t1[j]);
+            *reinterpret_cast<float2 *>(&dl[2 * i]) = make_float2(v[16 + j], v[24 + j]);
         }
     }
     if (OUT == 2) {
         wave_sync();
-        const int upb = 32 * n_out;                         // 16-byte units of one block of the stream
+        const int upb = 32 * n_out;                             // 16-byte units of one block of the stream
         int16_t *dst = W.pcm16 + blk_index * (size_t)n_out * 256;
 #pragma unroll
         for (int it = 0; it < 3; it++) {
@@ -647,9 +833,9 @@ __device__ __forceinline__ void xform_part_c(WgLDS &L, const WgParams &W, const 
     }
 }
 
-#pragma clang fp contract(off)
-
 }  // namespace wg
+
+using namespace wg;
 
 // OUT 0: coefficient planes (and block-switch flags) to HBM, for stage taps and the unfused paths
 // OUT 1: float PCM planes          OUT 2: interleaved s16 PCM
@@ -657,9 +843,10 @@ template <int OUT>
 __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
 {
     __shared__ WgLDS L;
+    __shared__ ParserState S;
     extern __shared__ uint32_t frw[];
     const DecodeParams &P = W.d;
-    const int tid = threadIdx.x, lane = tid & 63, l8 = tid & 7;
+    const int tid = threadIdx.x, lane0 = tid & 63, lane = lane0;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
     const FrameBits FB{frw, (uint32_t)((P.frame_bytes + 3) >> 2) + 2u};
     const int in_lfe = P.lfeon ? 1 : 0;
@@ -668,18 +855,24 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
 
     // ---- constant tables ----
     for (int i = tid; i < 256; i += 512) { L.la_neg[i] = P.tab->la_neg[i]; L.band_of_bin[i] = P.tab->band_of_bin[i]; L.win[i] = W.window[i]; }
-    if (tid < 64) L.width[tid] = P.tab->width[tid];
+    if (tid < 64) {                                                  // row-byte form of the width table: see slot_census
+        const int w = P.tab->width[tid];
+        L.width[tid] = (int8_t)(w >= 0 ? w : -32 * w);
+    }
+    if (tid < 128) {
+        const uint32_t k1 = (uint32_t)tid >> 5, nbp = (uint32_t)tid & 31u;
+        const uint32_t qbase = k1 == 1 ? 0u : k1 == 2 ? 96u : k1 == 3 ? 480u : nbp == 3 ? 736u : nbp == 4 ? 744u : 0u;
+        const uint32_t per = k1 == 3 ? 2u : k1 ? 3u : 0u, obits = k1 == 1 ? 5u : k1 ? 7u : 0u;
+        const uint32_t coded = (k1 || nbp == 3 || nbp == 4) ? 1u : 0u;
+        L.desc[tid] = qbase | (per << 10) | (obits << 12) | (coded << 15);
+    }
     if (tid < 30) L.band_end[tid] = P.tab->band_end[tid];
     if (tid < 50) L.hth[tid] = 0;
     for (int i = tid; i < 760; i += 512) L.qtab[i] = P.tab->qtab[i];
     if (tid < 128) { L.twl[tid] = W.tw_long[tid]; L.tws[tid] = W.tw_short[tid]; }
-    int hth_fscod = -1;
+    if (tid == 0) S.hth_fscod = -1;
 
     // transformer: 8-lane group g = output plane g (groups past n_out shadow plane 0 and store nothing)
-    const int xgroup = lane >> 3;
-    const bool xstore = xgroup < n_out;
-    const int xo = xstore ? xgroup : 0;
-    float2 *xex = L.ex + xo * EX_GROUP;
 
     for (int s = blockIdx.x; s < P.n_streams; s += gridDim.x) {
         // ---- per-stream state ----
@@ -692,27 +885,18 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
             const float *dsrc = W.delay + (size_t)sslot * W.delay_stride;
             for (int i = tid; i < n_out * 128; i += 512) (&L.dly[0][0])[i] = dsrc[i];
         }
-        St st;
-        st.fscod = st.halfrate = st.acmod = st.lfeon = 0;
-        st.nf = 0;
-        st.clev = st.slev = st.level = st.dynrng = 0.f;
-        st.output = 0;
-        st.dynrnge = 1;
-        st.chincpl = st.phsflginu = st.cplstrtmant = st.cplendmant = st.ncplbnd = st.cplstrtbnd = 0;
-        st.cplbndstrc = 0;
-        st.rematflg = 0;
-        for (int i = 0; i < 5; i++) st.endmant[i] = 0;
-        st.bai = st.csnroffst = 0;
-        for (int i = 0; i < 7; i++) st.cbai[i] = 0;
-        for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
-        st.cplfleak = st.cplsleak = 0;
-        st.lfsr = 0;
-        uint32_t lfsr_idx = 0;                                       // position in the dither generator's cycle
-        bool lfsr_live = false;
         if (wave == W_PARSE) {
-            st.lfsr = (uint32_t)P.lfsr_state[sslot];
-            lfsr_live = st.lfsr != 0;
-            lfsr_idx = (uint32_t)P.lfsr_idx[st.lfsr];
+            const int hf = ldsu(S.hth_fscod);
+            for (int i = lane; i < (int)(sizeof(ParserState) / 4); i += 64) reinterpret_cast<uint32_t *>(&S)[i] = 0u;
+            wave_sync();
+            if (lane < 6) S.deltbae[lane] = 2;
+            const uint32_t state = (uint32_t)P.lfsr_state[sslot];
+            if (lane == 0) {
+                S.dynrnge = 1;
+                S.hth_fscod = hf;
+                S.lfsr_live = state != 0;
+                S.lfsr_idx = (uint32_t)P.lfsr_idx[state];
+            }
         }
 
         for (int f = 0; f < P.frames_per_stream; f++) {
@@ -733,99 +917,48 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                 }
                 if (tid == 0) L.exp_err = 0;
             }
+            STAMP(0);
             wg_barrier();
+            STAMP(1);
 
-            // ---- frame header + block 0 (parser alone) ----
-            uint32_t status = 0, reuse0 = 0;
-            bool frame_dead = false;
-            Rd rd{FB, 0, ~0u, 0, 0};
-            ParseCarry pc;
-            pc.cplexpstr = pc.lfeexpstr = pc.chexp = pc.redo = 0;
+            // ---- frame header + side information of block 0 (parser alone) ----
             if (wave == W_PARSE) {
-                bool hdr_ok = true;                                  // a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205)
-                {
-                    const uint32_t w0 = rfl(frw[0]), w1 = rfl(frw[1]);
-                    const int b4 = (w1 >> 24) & 0xff, b5 = (w1 >> 16) & 0xff, b6 = (w1 >> 8) & 0xff;
-                    if ((w0 >> 16) != 0x0b77) hdr_ok = false;
-                    if (b5 >= 0x60) hdr_ok = false;
-                    if ((b4 & 63) >= 38 || (b4 & 0xc0) == 0xc0) hdr_ok = false;
-                    if (hdr_ok) {
-                        st.fscod = b4 >> 6;
-                        const int bsid = b5 >> 3;
-                        st.halfrate = bsid < 9 ? 0 : bsid - 8;
-                        st.acmod = b6 >> 5;
-                        if (st.acmod != P.acmod) hdr_ok = false;
-                        const int code = b4 & 63, rate = k_kbps[code >> 1];
-                        const int fbytes = st.fscod == 0 ? 4 * rate : st.fscod == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
-                        if (fbytes > P.frame_bytes) hdr_ok = false;
-                    }
-                }
-                if (hdr_ok) {
-                    int acmod = st.acmod;
-                    rd.pos = 6 * 8 + 3;
-                    if (acmod == 2 && rd.get(2) == 2) acmod = 10;                 // dsurmod -> DOLBY
-                    st.clev = st.slev = 0.f;
-                    if ((acmod & 1) && acmod != 1) st.clev = k_clev[rd.get(2)];
-                    if (acmod & 4) st.slev = k_slev[rd.get(2)];
-                    st.lfeon = rd.get(1);
-                    if (st.lfeon != P.lfeon) hdr_ok = false;
-                    float level = P.level;
-                    st.output = a52_downmix_init_hd(acmod, P.req_flags, &level, st.clev, st.slev);
-                    if (st.output < 0) hdr_ok = false;
-                    if (hdr_ok) {
-                        if (st.lfeon && (P.req_flags & AC3MI_LFE)) st.output |= AC3MI_LFE;
-                        st.dynrng = st.level = level * 2;
-                        st.dynrnge = P.dynrng_on;
-                        for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
-                        int twice = !acmod;
-                        do {
-                            rd.get(5);
-                            if (rd.get(1)) rd.get(8);
-                            if (rd.get(1)) rd.get(8);
-                            if (rd.get(1)) rd.get(7);
-                        } while (twice--);
-                        rd.get(2);
-                        if (rd.get(1)) rd.get(14);
-                        if (rd.get(1)) rd.get(14);
-                        if (rd.get(1)) {
-                            int len = rd.get(6);
-                            do rd.get(8); while (len--);
-                        }
-                        st.nf = k_nfchans[st.acmod];
-                        if (hth_fscod != st.fscod) {
-                            if (lane < 50) L.hth[lane] = P.tab->hth[st.fscod][lane];
-                            hth_fscod = st.fscod;
-                        }
-                        status |= (uint32_t)st.output << 16;
-                    }
-                }
-                if (!hdr_ok) { status |= 0x100u; frame_dead = true; }
+                PSET(S.status, 0u);
+                PSET(S.reuse0, 0u);
+                const bool ok = parse_frame_header(FB, frw, S, L.hth, P, lane);
+                PSET(S.frame_dead, ok ? 0 : 1);
+                if (!ok) PSET(S.status, 0x100u);
                 BlkInfo &B0 = L.bi[0];
-                if (!frame_dead) {
-                    parse_block_a(rd, st, B0, L.bi[1], pc, 0, reuse0, lane);
+                if (ok) {
+                    parse_block_a(FB, S, B0, L.bi[1], 0, lane);
                     wave_sync();
-                    parse_block_b(rd, st, B0, L, pc, 0, reuse0, lane);
-                } else if (lane == 0) B0.err = 1;
-                if (lane == 0) {
-                    B0.lfsr_i0 = lfsr_idx;
-                    B0.lfsr_live = lfsr_live ? 1 : 0;
-                }
+                    parse_block_b(FB, S, B0, L.deltba, 0, lane);
+                } else PSET(B0.err, 1);
                 wave_sync();
-                if (lane == 0) L.blkswm_hist[0] = frame_dead ? 0 : B0.blkswm;
+                if (lane == 0) {
+                    B0.lfsr_i0 = S.lfsr_idx;
+                    B0.lfsr_live = S.lfsr_live;
+                    L.blkswm_hist[0] = ok ? B0.blkswm : 0;
+                }
             }
 
+            STAMP(2);
             // ---- six blocks ----
-            cf xr[16];                                               // transformer: block blk-1 between its parts
-            FirstTail xft;
-            int xsw = 0;
             for (int blk = 0; blk < 6; blk++) {
                 const BlkInfo &B = L.bi[blk & 1];
                 BlkInfo &Bn = L.bi[(blk + 1) & 1];
                 wg_barrier();                                        // ---- B1: B is valid, the planes hold block blk-1 ----
+                STAMP(4 + 8 * blk);
+                const int lane = opaque(lane0), l8 = lane & 7;
+                const int xgroup = lane >> 3;
+                const bool xstore = xgroup < n_out;
+                const int xo = xstore ? xgroup : 0;
+                float2 *xex = L.ex + xo * EX_GROUP;
                 const int err_side = ldsu(B.err);
                 const int chincpl = err_side ? 0 : ldsu(B.chincpl);
                 const int cplstrt = ldsu(B.cplstrtmant), cplend = ldsu(B.cplendmant);
                 const int my_end = wave < 5 ? ldsu(B.endmant[wave < 5 ? wave : 0]) : 7;
+                int xsw = 0;
                 if (wave <= W_LFE) {
                     if (!err_side) {
                         if (wave < nf) {
@@ -847,13 +980,15 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                         int8_t *tb = P.tap_bap + (fidx * 6 + blk) * 7 * 256;
                         for (int i = lane; i < 256; i += 64) {       // (the LFE row is short)
                             const bool in = wave != 5 || i < LFE_ROW;
+                            const int bb = in ? L.bap[row_off(wave) + i] : 0;
                             te[wave * 256 + i] = in ? L.exp[row_off(wave) + i] : 0;
-                            tb[wave * 256 + i] = in ? L.bap[row_off(wave) + i] : 0;
+                            tb[wave * 256 + i] = (int8_t)(bb >= 32 ? -(bb >> 5) : bb);          // liba52's form: -1 / -2 / -3 for grouped codes
                         }
                         if (wave == W_LFE)
                             for (int i = lane; i < 256; i += 64) {
+                                const int bb = L.bap[row_off(6) + i];
                                 te[6 * 256 + i] = L.exp[row_off(6) + i];
-                                tb[6 * 256 + i] = L.bap[row_off(6) + i];
+                                tb[6 * 256 + i] = (int8_t)(bb >= 32 ? -(bb >> 5) : bb);
                             }
                     }
                 } else if (wave == W_XFORM && blk > 0) {
@@ -867,49 +1002,61 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                     } else {
                         const int fb = xo - in_lfe;
                         xsw = fb >= 0 ? (L.blkswm_hist[blk - 1] >> fb) & 1 : 0;
-                        xform_part_a(L, xo, xsw, l8, xex, xr);
+                        xform_part_a(L, xo, xsw, l8, xex);
                     }
                 }
+                STAMP(5 + 8 * blk);
                 wg_barrier();                                        // ---- B2: censuses and exponent verdicts are in; planes are free ----
+                STAMP(6 + 8 * blk);
                 const int err = err_side | ldsu(L.exp_err);
                 BinRegs R, R2;
-                SegBase sb, sb2;
+                int cpl_mult = 0;
                 if (wave <= W_LFE) {
                     if (!err) {
                         if (wave < nf) {
-                            sb = segment_prefix(L, B, wave, nf, P.lfeon != 0, lane);
+                            const SegBase sb = segment_prefix(L, B, wave, nf, P.lfeon != 0, lane);
                             slot_t2a(L, FB, frw, wave, 0, my_end, sb, R, lane);
                         } else if (wave == W_LFE) {
                             if (chincpl) {
-                                sb = segment_prefix(L, B, 6, nf, P.lfeon != 0, lane);
+                                const SegBase sb = segment_prefix(L, B, 6, nf, P.lfeon != 0, lane);
+                                cpl_mult = sb.mult;
                                 slot_t2a(L, FB, frw, 6, cplstrt, cplend, sb, R, lane);
                             }
                             if (P.lfeon) {
-                                sb2 = segment_prefix(L, B, 5, nf, P.lfeon != 0, lane);
+                                const SegBase sb2 = segment_prefix(L, B, 5, nf, P.lfeon != 0, lane);
                                 slot_t2a(L, FB, frw, 5, 0, 7, sb2, R2, lane);
                             }
                         }
                     }
                 } else if (wave == W_PARSE) {
+                    int dead = ldsu(S.frame_dead);
                     if (err) {
-                        status |= 1u << blk;
-                        frame_dead = true;
+                        PSET(S.status, (uint32_t)ldsu((const int &)S.status) | (1u << blk));
+                        PSET(S.frame_dead, 1);
+                        dead = 1;
                         if (lane == 0) L.blkswm_hist[blk] = 0;
                     } else {
-                        sb = segment_prefix(L, B, 0, nf, P.lfeon != 0, lane);
-                        if (lfsr_live && sb.total_draws) lfsr_idx = (lfsr_idx + (uint32_t)sb.total_draws) % 65535u;
-                        rd.pos = (uint32_t)ldsu(B.mant_pos) + sb.total_bits;
+                        const SegBase sb = segment_prefix(L, B, 0, nf, P.lfeon != 0, lane);
+                        if (ldsu(S.lfsr_live) && sb.total_draws)
+                            PSET(S.lfsr_idx, ((uint32_t)ldsu((const int &)S.lfsr_idx) + (uint32_t)sb.total_draws) % 65535u);
+                        PSET(S.pos, (uint32_t)ldsu(B.mant_pos) + sb.total_bits);
                     }
                     if (blk < 5) {
-                        if (!frame_dead) parse_block_a(rd, st, Bn, B, pc, blk + 1, reuse0, lane);
-                        else if (lane == 0) Bn.err = 1;
+#ifdef WG_STAMPS
+                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane, (W.stamps && blockIdx.x == 0 && s == (int)gridDim.x && f == 0 && blk == 2) ? W.stamps + wave * 64 + 56 : nullptr);
+#else
+                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane);
+#endif
+                        else PSET(Bn.err, 1);
                     }
                 } else if (OUT != 0 && blk > 0) {
-                    xft = FirstTail{};
-                    if (!xsw) imdct_long_second_half(xr, xft);
-                    else imdct_short_second_half(xr, xft);
+                    const int fb = xo - in_lfe;
+                    xsw = fb >= 0 ? (L.blkswm_hist[blk - 1] >> fb) & 1 : 0;
+                    xform_part_b(xsw, l8, xex);
                 }
+                STAMP(7 + 8 * blk);
                 wg_barrier();                                        // ---- B3: the open codes are published ----
+                STAMP(8 + 8 * blk);
                 const int need_fix = err ? 0 : ldsu(B.need_fix);
                 if (wave <= W_LFE) {
                     const uint32_t i0 = (uint32_t)ldsu((const int &)B.lfsr_i0);
@@ -921,16 +1068,19 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                             const float g = ldsf(B.gain[wave < 5 ? wave : 0]);
                             const int dith = (dithmask >> wave) & 1;
                             int cd = R.cd;
+                            const bool any_dither = dith && live;
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const int bin = 4 * lane + j;
-                                const bool act = bin < my_end;
-                                const int w = act ? (int)(int8_t)(R.bap4 >> (8 * j)) : -9;
+                                const bool zero = bin < my_end && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
                                 const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
-                                float q = bin_q(L, R, j, w);
-                                if (w == 0 && dith) { q = (float)(live ? dither_at(P.lfsr_seq, i0, cd) : 0); cd++; }
-                                const float v = q * (sf_of(e) * g);
-                                out[j] = act ? v : 0.f;
+                                float q = bin_q(L, R, j);
+                                if (any_dither && __any(zero)) {          // wave-uniform: skip the table access when no lane draws
+                                    const float dv = (float)dither_at(P.lfsr_seq, i0, cd);
+                                    q = zero ? dv : q;
+                                }
+                                cd += (zero && dith) ? 1 : 0;
+                                out[j] = q * (sf_of(e) * g);          // (bins outside the channel have no bits: q = 0)
                             }
                         }
                         *reinterpret_cast<float4 *>(L.planes + (wave + in_lfe) * PLANE + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
@@ -940,13 +1090,11 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const int bin = 4 * lane + j;
-                                const bool act = bin >= cplstrt && bin < cplend;
-                                const int w = act ? (int)(int8_t)(R.bap4 >> (8 * j)) : -9;
+                                const bool zero = bin >= cplstrt && bin < cplend && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
                                 const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
-                                const float q = bin_q(L, R, j, w);
-                                L.cplq[bin] = q * sf_of(e);
+                                L.cplq[bin] = bin_q(L, R, j) * sf_of(e);
                                 L.cplcd[bin] = (int16_t)cd;
-                                if (w == 0) cd += sb.mult;
+                                cd += zero ? cpl_mult : 0;
                             }
                         }
                         if (P.lfeon) {
@@ -955,12 +1103,8 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                                 const float g = ldsf(B.lfe_gain);
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    const int bin = 4 * lane + j;
-                                    const bool act = bin < 7;
-                                    const int w = act ? (int)(int8_t)(R2.bap4 >> (8 * j)) : -9;
                                     const int e = (int)((R2.exp4 >> (8 * j)) & 0xffu);
-                                    const float v = bin_q(L, R2, j, w) * (sf_of(e) * g);
-                                    out[j] = act ? v : 0.f;
+                                    out[j] = bin_q(L, R2, j) * (sf_of(e) * g);
                                 }
                             }
                             *reinterpret_cast<float4 *>(L.planes + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
@@ -968,17 +1112,19 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                     }
                 } else if (wave == W_PARSE) {
                     if (blk < 5) {
-                        if (!frame_dead) parse_block_b(rd, st, Bn, L, pc, blk + 1, reuse0, lane);
-                        if (lane == 0) {
-                            Bn.lfsr_i0 = lfsr_idx;
-                            Bn.lfsr_live = lfsr_live ? 1 : 0;
-                        }
+                        const int dead = ldsu(S.frame_dead);
+                        if (!dead) parse_block_b(FB, S, Bn, L.deltba, blk + 1, lane);
                         wave_sync();
-                        if (lane == 0) L.blkswm_hist[blk + 1] = frame_dead ? 0 : Bn.blkswm;
+                        if (lane == 0) {
+                            Bn.lfsr_i0 = S.lfsr_idx;
+                            Bn.lfsr_live = S.lfsr_live;
+                            L.blkswm_hist[blk + 1] = dead ? 0 : Bn.blkswm;
+                        }
                     }
                 } else if (OUT != 0 && blk > 0) {
-                    xform_part_c<OUT>(L, W, xft, xo, l8, lane, xstore, fidx * 6 + (blk - 1));
+                    xform_part_c<OUT>(L, W, xo, l8, lane, xstore, xex, fidx * 6 + (blk - 1));
                 }
+                STAMP(9 + 8 * blk);
                 if (need_fix) {
                     wg_barrier();                                    // ---- B4: every plane and the coupling channel are in LDS ----
                     if (wave < nf && ((chincpl >> wave) & 1)) {
@@ -1008,17 +1154,15 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                         }
                     }
                     const int rematflg = ldsu(B.rematflg);
-                    if (rematflg) {                                  // (a coupled channel's share lies above the rematrixed bins)
-                        if (wave == 0) {                             // rematrix: parse.c:837-865
-                            const int rend = ldsu(B.remat_end);
-                            float *p0 = L.planes + in_lfe * PLANE, *p1 = p0 + PLANE;
-                            for (int bin = 13 + lane; bin < rend; bin += 64) {
-                                const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
-                                if ((rematflg >> band) & 1) {
-                                    const float a = p0[bin], v = p1[bin];
-                                    p0[bin] = a + v;
-                                    p1[bin] = a - v;
-                                }
+                    if (rematflg && wave == 0) {                     // rematrix: parse.c:837-865 (a coupled channel's share lies above these bins)
+                        const int rend = ldsu(B.remat_end);
+                        float *p0 = L.planes + in_lfe * PLANE, *p1 = p0 + PLANE;
+                        for (int bin = 13 + lane; bin < rend; bin += 64) {
+                            const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
+                            if ((rematflg >> band) & 1) {
+                                const float a = p0[bin], v = p1[bin];
+                                p0[bin] = a + v;
+                                p1[bin] = a - v;
                             }
                         }
                     }
@@ -1026,7 +1170,13 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
             }
             // ---- the transformer owes block 5 ----
             wg_barrier();
+            STAMP(52);
             if (wave == W_XFORM) {
+                const int lane = opaque(lane0), l8 = lane & 7;
+                const int xgroup = lane >> 3;
+                const bool xstore = xgroup < n_out;
+                const int xo = xstore ? xgroup : 0;
+                float2 *xex = L.ex + xo * EX_GROUP;
                 if (OUT == 0) {
                     float *cblk = P.coef + (fidx * 6 + 5) * (size_t)P.n_in * 256;
                     for (int c = 0; c < P.n_in; c++)
@@ -1034,19 +1184,22 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                     if (P.blksw && lane < nf) P.blksw[(fidx * 6 + 5) * nf + lane] = (uint8_t)((L.blkswm_hist[5] >> lane) & 1);
                 } else {
                     const int fb = xo - in_lfe;
-                    xsw = fb >= 0 ? (L.blkswm_hist[5] >> fb) & 1 : 0;
-                    xform_part_a(L, xo, xsw, l8, xex, xr);
-                    xft = FirstTail{};
-                    if (!xsw) imdct_long_second_half(xr, xft);
-                    else imdct_short_second_half(xr, xft);
-                    xform_part_c<OUT>(L, W, xft, xo, l8, lane, xstore, fidx * 6 + 5);
+                    const int xsw = fb >= 0 ? (L.blkswm_hist[5] >> fb) & 1 : 0;
+                    xform_part_a(L, xo, xsw, l8, xex);
+                    xform_part_b(xsw, l8, xex);
+                    xform_part_c<OUT>(L, W, xo, l8, lane, xstore, xex, fidx * 6 + 5);
                 }
             }
-            if (wave == W_PARSE && lane == 0) P.status[fidx] = status | ((status & 0x100u) ? 0x3fu : 0u) | (reuse0 ? 0x200u : 0u);
+            if (wave == W_PARSE && lane == 0) {
+                const uint32_t st = S.status;
+                P.status[fidx] = st | ((st & 0x100u) ? 0x3fu : 0u) | (S.reuse0 ? 0x200u : 0u);
+            }
+            STAMP(53);
             wg_barrier();                                            // the frame buffer and the planes are free
+            STAMP(54);
         }
         // ---- carry-over state of the stream ----
-        if (wave == W_PARSE && lane == 0) P.lfsr_state[sslot] = lfsr_live ? P.lfsr_seq[lfsr_idx] : (uint16_t)0;
+        if (wave == W_PARSE && lane == 0) P.lfsr_state[sslot] = S.lfsr_live ? P.lfsr_seq[S.lfsr_idx] : (uint16_t)0;
         if (OUT != 0) {
             float *ddst = W.delay + (size_t)sslot * W.delay_stride;
             for (int i = tid; i < n_out * 128; i += 512) ddst[i] = (&L.dly[0][0])[i];
@@ -1093,6 +1246,7 @@ hipError_t launch_decode_wg(const DeviceTables &tab, const DecodeLaunch &D, cons
     W.bias = 0.f;
     W.n_out = P.n_in;
     for (int i = 0; i < 6; i++) W.wslot[i] = (int8_t)i;
+    W.stamps = nullptr;
     if (D.n_streams <= 0 || D.frames_per_stream <= 0) return hipSuccess;
     const size_t fr_bytes = (size_t)(((D.frame_bytes + 3) >> 2) + 6) * 4;
     // persistent grid: as many workgroups as the chip holds at once (each walks streams blockIdx.x, + gridDim.x, ...)
@@ -1105,6 +1259,34 @@ hipError_t launch_decode_wg(const DeviceTables &tab, const DecodeLaunch &D, cons
         grid_cap = occ * cus;
     }
     int grid = D.n_streams < grid_cap ? D.n_streams : grid_cap;
+#ifdef WG_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc((void **)&d_stamps, 8 * 64 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_stamps, 0, 8 * 64 * sizeof(unsigned long long), stream);
+    W.stamps = d_stamps;
+    struct Dump {
+        unsigned long long *d; hipStream_t st;
+        ~Dump() {
+            unsigned long long h[8 * 64];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+            if (const char *path = getenv("AC3MI_WG_STAMPS")) {
+                FILE *fp = fopen(path, "a");
+                if (fp) {
+                    unsigned long long t0 = ~0ull;
+                    for (int i = 0; i < 8 * 64; i++) if (h[i] && h[i] < t0) t0 = h[i];
+                    for (int w = 0; w < 8; w++) {
+                        fprintf(fp, "wave %d:", w);
+                        for (int i = 0; i < 64; i++) fprintf(fp, " %lld", h[w * 64 + i] ? (long long)(h[w * 64 + i] - t0) : -1ll);
+                        fprintf(fp, "\n");
+                    }
+                    fprintf(fp, "\n");
+                    fclose(fp);
+                }
+            }
+        }
+    } dump{d_stamps, stream};
+#endif
     if (!X) {
         hipLaunchKernelGGL(decode_wg_kernel<0>, dim3(grid), dim3(512), fr_bytes, stream, W);
         return hipGetLastError();

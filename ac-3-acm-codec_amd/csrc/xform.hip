@@ -66,8 +66,8 @@ __device__ __forceinline__ void load_long(const float *plane, int l8, float sign
     for (int n = 0; n < 16; n++) v[n] = p[8 * n];
 #pragma unroll
     for (int n = 0; n < 16; n++) {
-        xa[n] += sign * v[n].x;                     // X[2m]
-        xb[n] += sign * mirror8(v[15 - n].y);       // X[255-2m] = X[2m'+1], m' = 127-m
+        xa[n] = __builtin_fmaf(sign, v[n].x, xa[n]);                     // X[2m]
+        xb[n] = __builtin_fmaf(sign, mirror8(v[15 - n].y), xb[n]);       // X[255-2m] = X[2m'+1], m' = 127-m
     }
 }
 
@@ -79,8 +79,8 @@ __device__ __forceinline__ void load_short(const float *plane, int l8, float sig
     const float *pb = plane + 254 + f - 4 * n2;
 #pragma unroll
     for (int n = 0; n < 16; n++) {
-        xa[n] += sign * pa[16 * n];
-        xb[n] += sign * pb[-16 * n];
+        xa[n] = __builtin_fmaf(sign, pa[16 * n], xa[n]);
+        xb[n] = __builtin_fmaf(sign, pb[-16 * n], xb[n]);
     }
 }
 
@@ -237,10 +237,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             const float2 wlo = *reinterpret_cast<const float2 *>(&lds_win[2 * i]);         // w[2i], w[2i+1]
             const float2 whi = *reinterpret_cast<const float2 *>(&lds_win[254 - 2 * i]);   // w[254-2i], w[255-2i]
             float2 lo, hi;
-            lo.x = ft.f0[j] * wlo.x + (dl[j].x * whi.y + P.bias);          // out[2i]
-            lo.y = ft.f1[j] * wlo.y + (dl[j].y * whi.x + P.bias);          // out[2i+1]
-            hi.x = dl[j].y * wlo.y + P.bias - ft.f1[j] * whi.x;            // out[254-2i]
-            hi.y = dl[j].x * wlo.x + P.bias - ft.f0[j] * whi.y;            // out[255-2i]
+            window_pair(ft.f0[j], ft.f1[j], dl[j], wlo, whi, P.bias, lo, hi);
             if (emit && !S16) {
                 *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
                 *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;

@@ -40,9 +40,12 @@ struct cf { float re, im; };
 
 __device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+// Fused multiply-adds are written out (and the translation units that include this header are built with
+// -ffp-contract=off), so that every kernel that inlines this arithmetic - the transform kernel of xform.hip and the fused
+// decoder of decode_wg.hip, in all their instantiations - produces the same bits from the same coefficients.
 __device__ __forceinline__ cf cmul(cf a, float cr, float ci)
 {
-    return {a.re * cr - a.im * ci, a.re * ci + a.im * cr};
+    return {__builtin_fmaf(a.re, cr, -(a.im * ci)), __builtin_fmaf(a.re, ci, a.im * cr)};
 }
 __device__ __forceinline__ cf cmul(cf a, cf c) { return cmul(a, c.re, c.im); }
 
@@ -127,7 +130,7 @@ constexpr int EX_WAVE = 8 * EX_GROUP;            // float2 per wavefront
 
 // v[k1] (k1 = 0..15) held by lane `l8` of the group  ->  r[0..7] = column l8,
 // r[8..15] = column 15-l8 of the 8x16 matrix [lane][k1].  `ex` = this group's region.
-__device__ __forceinline__ void transpose_8x16(float2 *ex, int l8, const cf (&v)[16], cf (&r)[16])
+__device__ __forceinline__ void transpose_8x16_put(float2 *ex, int l8, const cf (&v)[16])
 {
     float4 *row = reinterpret_cast<float4 *>(ex + l8 * EX_ROW);
 #pragma unroll
@@ -135,6 +138,9 @@ __device__ __forceinline__ void transpose_8x16(float2 *ex, int l8, const cf (&v)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void transpose_8x16_get(const float2 *ex, int l8, cf (&r)[16])
+{
 #pragma unroll
     for (int l = 0; l < 8; l++) {
         float2 a = ex[l * EX_ROW + l8];
@@ -144,6 +150,11 @@ __device__ __forceinline__ void transpose_8x16(float2 *ex, int l8, const cf (&v)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void transpose_8x16(float2 *ex, int l8, const cf (&v)[16], cf (&r)[16])
+{
+    transpose_8x16_put(ex, l8, v);
+    transpose_8x16_get(ex, l8, r);
 }
 
 // e^{-j pi k/16}, k = 0..7 and e^{-j pi k/8}, k = 0..3
@@ -169,8 +180,7 @@ __device__ __forceinline__ cf tw_at(const float2 *tw, int k) { float2 t = tw[k];
 // The two halves of a transform (the fused decoder, decode_wg.hip, puts a workgroup barrier between them):
 // first half = pre-twiddle, DFT-16, lane twiddles, 8x16 transpose; common to the long and the short block.
 template <typename TW>
-__device__ __forceinline__ void imdct_first_half(const float (&xa)[16], const float (&xb)[16], const TW &tw,
-                                                 float2 *ex, int l8, cf (&r)[16])
+__device__ __forceinline__ void imdct_first_half_put(const float (&xa)[16], const float (&xb)[16], const TW &tw, float2 *ex, int l8)
 {
     cf v[16];
 #pragma unroll
@@ -178,7 +188,24 @@ __device__ __forceinline__ void imdct_first_half(const float (&xa)[16], const fl
     dft16(v);
 #pragma unroll
     for (int k = 0; k < 16; k++) v[k] = cmul(v[k], tw_at(tw, k));
-    transpose_8x16(ex, l8, v, r);
+    transpose_8x16_put(ex, l8, v);
+}
+template <typename TW>
+__device__ __forceinline__ void imdct_first_half(const float (&xa)[16], const float (&xb)[16], const TW &tw,
+                                                 float2 *ex, int l8, cf (&r)[16])
+{
+    imdct_first_half_put(xa, xb, tw, ex, l8);
+    transpose_8x16_get(ex, l8, r);
+}
+
+// window + overlap-add of one output pair position (both halves of the block) - the same expression in every kernel:
+//   out[p] = first[p] w[p] + prev_tail[p] w[255-p] + bias,  out[255-p] = -first[p] w[255-p] + prev_tail[p] w[p] + bias
+__device__ __forceinline__ void window_pair(float f0, float f1, float2 d, float2 wlo, float2 whi, float bias, float2 &lo, float2 &hi)
+{
+    lo.x = __builtin_fmaf(f0, wlo.x, __builtin_fmaf(d.x, whi.y, bias));        // out[2i]
+    lo.y = __builtin_fmaf(f1, wlo.y, __builtin_fmaf(d.y, whi.x, bias));        // out[2i+1]
+    hi.x = __builtin_fmaf(-f1, whi.x, __builtin_fmaf(d.y, wlo.y, bias));       // out[254-2i]
+    hi.y = __builtin_fmaf(-f0, whi.y, __builtin_fmaf(d.x, wlo.x, bias));       // out[255-2i]
 }
 
 __device__ __forceinline__ void imdct_long_second_half(cf (&r)[16], FirstTail &ft);

@@ -75,15 +75,18 @@ def test_wg_fused_pcm_float_and_s16(wg_engine, kind):
                 L.orc_convert_s16(H.P(np.ascontiguousarray(ref384[s, f, b]), H.fp), H.P(ref16, H.i16p), oflags)
                 worst = max(worst, int(np.abs(got[s, f, b].astype(np.int32) - ref16.astype(np.int32)).max()))
     assert worst <= 1, worst
-    # overlap tails of the fused path against the transform kernel's (same arithmetic, other translation unit)
+    # the fused path against front end + transform kernel (same arithmetic, other translation unit)
     wg_engine.set_decode_mode(1)
     delay1 = torch.zeros((S, 6, 128), dtype=torch.float32, device="cuda")
     st1 = torch.ones((S,), dtype=torch.int16, device="cuda")
     got1, _ = wg_engine.decode_s16_batch(desc, torch.from_numpy(frames).cuda(), delay1, st1)
     wg_engine.sync()
+    # (the transform's fused multiply-adds are written out in xform_core.h and both translation units are built with
+    # -ffp-contract=off: the fused decoder and the transform kernel agree bit for bit, so results do not depend on which
+    # variant a batch shape selects)
     assert torch.equal(st.cpu(), st1.cpu())
-    assert float((delay.cpu() - delay1.cpu()).abs().max()) <= 4e-6
-    assert int((got1.cpu().to(torch.int32) - torch.from_numpy(got).to(torch.int32)).abs().max()) <= 1
+    assert torch.equal(delay.cpu(), delay1.cpu())
+    assert torch.equal(got1.cpu(), torch.from_numpy(got))
 
 
 PACKER_CASES = [(7, 1, 0, 8, 36), (7, 0, 0, 8, 34), (2, 0, 0, 8, 30), (2, 0, 1, 8, 31), (0, 0, 2, 8, 28), (1, 0, 0, 8, 24),
@@ -123,9 +126,12 @@ def test_wg_packer_streams(wg_engine, acmod, lfe, fscod, bsid, fsz):
     assert np.array_equal(a[3]["blksw"], b[3]["blksw"])
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))          # same planes through the same transform kernel
     want = np.stack([H.orc_decode(frames[s], flags, 1.0, 0.0)[0] for s in range(S)])
+    # random mantissas at random exponents / dynrng gains give |PCM| far above +-1.0 full scale: the 1e-6 bar is relative
+    # to full scale, so scale it by the signal level where that exceeds 1 (as tests/test_packer_streams.py does)
+    scale_rms, scale_max = max(1.0, H.rms(want)), max(1.0, float(np.abs(want).max()))
     for got in (b[0], c[0]):
         err = got.astype(np.float64) - want
-        assert H.rms(err) <= 1e-6 and np.abs(err).max() <= 8e-6, (H.rms(err), np.abs(err).max())
+        assert H.rms(err) <= 1e-6 * scale_rms and np.abs(err).max() <= 1e-5 * scale_max, (H.rms(err), np.abs(err).max())
 
 
 @pytest.mark.parametrize("seed,acmod,lfe", [(3, 7, 1), (4, 2, 0), (5, 5, 1), (6, 3, 0)])
