@@ -67,6 +67,7 @@ struct PackParams {
     uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
     int c1, c2;                 // CRC chunk bytes per lane
     int frw;                    // dwords of the frame buffer in (dynamic) LDS: the frame + 256 bytes of headroom, multiple of 4
+    int marker;                 // the reference's "member already merged" value, 128 (:1375-1413); AC3MI_ENC_MARKER: test aid
 };
 
 
@@ -88,6 +89,10 @@ struct alignas(16) PackLDS {
     uint8_t strat[6][6];
     uint8_t band_of_bin[256];
     uint16_t crc_tab[256];
+    // grouped codes whose 16-bit value came out as 128, the reference's "member already merged" marker (:1466-1480):
+    // kind << 16 | group, first attempt of a block's packing
+    uint32_t coll[32];
+    int ncoll;
 };
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
@@ -1136,6 +1141,20 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                 if (nfbw == 0) { t_ch = 0; t_bin = lane; }
                 int nx_coef = lane < T ? mdb[t_ch * 256 + t_bin] : 0;
                 int nx_exp = lane < T ? Eb[t_ch * 256 + t_bin] : 0;
+                // The reference quantises a whole block before it writes it, and does not write a grouped code whose
+                // (out-of-contract, garbage) 16-bit value equals 128: everything after it then sits 5 or 7 bits earlier.
+                // First attempt: nominal offsets; such codes are recorded, not written.  If there were any (practically
+                // never), the block's mantissa bits are erased and packed again with those fields left out.
+                const uint32_t pos_m = pos;
+                const uint32_t marker = (uint32_t)P.marker;
+                int dropped_known = 0;
+                if (lane == 0) L.ncoll = 0;
+#pragma unroll 1
+              for (int attempt = 0; attempt < 2; attempt++) {
+                t_ch = lane / nbc; t_bin = lane - t_ch * nbc;
+                if (nfbw == 0) { t_ch = 0; t_bin = lane; }
+                nx_coef = lane < T ? mdb[t_ch * 256 + t_bin] : 0;
+                nx_exp = lane < T ? Eb[t_ch * 256 + t_bin] : 0;
                 int b3 = 0, b5 = 0, b11 = 0;
 #pragma unroll 1
                 for (int k = 0; k < R; k++) {
@@ -1173,7 +1192,12 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                     const bool opens = grouped && mem == 0;
                     const int gbits = kind == 0 ? 5 : 7;
                     const int w = (int)(lut & 0x3ffu);
-                    const int nb = grouped ? (opens ? gbits : 0) : w;
+                    bool dropped = false;
+                    if (dropped_known) {                             // second attempt only
+                        const uint32_t key = ((uint32_t)kind << 16) | (uint32_t)grp;
+                        for (int q = 0; q < dropped_known; q++) dropped |= opens && L.coll[q] == key;
+                    }
+                    const int nb = grouped ? (opens && !dropped ? gbits : 0) : w;
                     const uint32_t bincl = wave_incl_scan_u32((uint32_t)nb);
                     const uint32_t off = pos + bincl - (uint32_t)nb;
                     const uint32_t gtot = wave_last(gincl);
@@ -1193,7 +1217,11 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                     WAVE_SYNC();
                     if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt) << 16);
                     WAVE_SYNC();
-                    if (grouped && mem == per - 1) { const uint32_t x = *slot; put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16); }
+                    if (grouped && mem == per - 1) {
+                        const uint32_t x = *slot;
+                        if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
+                        else if (attempt == 0) { const int q = atomicAdd(&L.ncoll, 1); if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
+                    }
 
                     b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
                     pos += wave_last(bincl);
@@ -1201,10 +1229,27 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                 // a trailing group that never got its last member is written as it stands
                 WAVE_SYNC();
                 if (lane == 0) {
-                    if (b3 % 3) { const uint32_t x = L.gtab[(b3 / 3) & 31]; put_bits(fr, P.frw, x & 0xffffu, 5, x >> 16); }
-                    if (b5 % 3) { const uint32_t x = L.gtab[32 + ((b5 / 3) & 31)]; put_bits(fr, P.frw, x & 0xffffu, 7, x >> 16); }
-                    if (b11 & 1) { const uint32_t x = L.gtab[64 + ((b11 >> 1) & 63)]; put_bits(fr, P.frw, x & 0xffffu, 7, x >> 16); }
+                    auto tail = [&](int kind, int grp, uint32_t x, int gbits) {
+                        if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
+                        else if (attempt == 0) { const int q = L.ncoll++; if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
+                    };
+                    if (b3 % 3) tail(0, b3 / 3, L.gtab[(b3 / 3) & 31], 5);
+                    if (b5 % 3) tail(1, b5 / 3, L.gtab[32 + ((b5 / 3) & 31)], 7);
+                    if (b11 & 1) tail(2, b11 >> 1, L.gtab[64 + ((b11 >> 1) & 63)], 7);
                 }
+                WAVE_SYNC();
+                const int ncoll = (int)__builtin_amdgcn_readfirstlane(L.ncoll);
+                if (attempt == 1 || ncoll == 0) break;
+                // erase the block's mantissa bits and pack them again without the dropped fields
+                {
+                    const uint32_t w0 = pos_m >> 5;
+                    if (lane == 0 && (pos_m & 31u)) fr[w0] &= ~(0xffffffffu >> (pos_m & 31u));
+                    for (uint32_t i = w0 + ((pos_m & 31u) ? 1u : 0u) + (uint32_t)lane; i < (uint32_t)P.frw; i += 64) fr[i] = 0u;
+                }
+                pos = pos_m;
+                dropped_known = ncoll < 32 ? ncoll : 32;
+                WAVE_SYNC();
+              }
             }
             WAVE_SYNC();
         }
@@ -1332,6 +1377,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.snr = E.ws_snr;
     P.memo = nullptr;
     P.frw = ((2 * fs + 256 + 15) / 16) * 4;
+    P.marker = getenv("AC3MI_ENC_MARKER") ? atoi(getenv("AC3MI_ENC_MARKER")) : 128;      // test aid (read per launch), see PackParams::marker
     static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
     const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
     if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {

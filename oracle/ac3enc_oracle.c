@@ -565,9 +565,23 @@ static inline int quant_asym(int c, int e, int qbits)
 
 /* ---------------- frame assembly (ac3enc.cpp:1113-1147, 1194-1502, 1599-1638) ---------------- */
 
+/* test aid: how often the out-of-contract corners were taken (negative shift in quant_sym; a grouped code whose garbage
+ * value equals the "already merged" marker 128 and is therefore not written, ac3enc.cpp:1466-1480) */
+static long dbg_collisions, dbg_negshift;
+/* the value ac3enc stores in the slots of merged members (128, ac3enc.cpp:1375-1413).  Test aid: a value that ordinary
+ * content produces as a code makes the "code equals marker -> not written" path (:1466-1480) testable. */
+static int merged_marker = 128;
+void orc_ac3enc_set_marker(int v) { merged_marker = v; }
+void orc_ac3enc_debug_counts(long *collisions, long *negshift)
+{
+    if (collisions) *collisions = dbg_collisions;
+    if (negshift) *negshift = dbg_negshift;
+}
+
 static void write_block(orc_ac3enc_t *s, bitw *w, int blk)
 {
     uint16_t q[MAXCH][256];
+    uint8_t opener[MAXCH][256];
     uint16_t *slot3 = NULL, *slot5 = NULL, *slot11 = NULL;
     int n3 = 0, n5 = 0, n11 = 0, ch, i;
 
@@ -619,25 +633,27 @@ static void write_block(orc_ac3enc_t *s, bitw *w, int blk)
         for (i = 0; i < s->nb_coefs[ch]; i++) {
             int c = s->mdct[blk][ch][i], e = s->enc_exp[blk][ch][i] - s->shift[blk][ch];
             int b = s->bap[blk][ch][i], v;
+            opener[ch][i] = (b == 1 && n3 == 0) || (b == 2 && n5 == 0) || (b == 4 && n11 == 0);
+            if (e < 0 && b >= 1 && b <= 5) __atomic_add_fetch(&dbg_negshift, 1, __ATOMIC_RELAXED);
             switch (b) {
             case 0: v = 0; break;
             case 1:
                 v = quant_sym(c, e, 3);
                 if (n3 == 0) { slot3 = &q[ch][i]; v = 9 * v; n3 = 1; }
-                else if (n3 == 1) { *slot3 += 3 * v; n3 = 2; v = 128; }
-                else { *slot3 += v; n3 = 0; v = 128; }
+                else if (n3 == 1) { *slot3 += 3 * v; n3 = 2; v = merged_marker; }
+                else { *slot3 += v; n3 = 0; v = merged_marker; }
                 break;
             case 2:
                 v = quant_sym(c, e, 5);
                 if (n5 == 0) { slot5 = &q[ch][i]; v = 25 * v; n5 = 1; }
-                else if (n5 == 1) { *slot5 += 5 * v; n5 = 2; v = 128; }
-                else { *slot5 += v; n5 = 0; v = 128; }
+                else if (n5 == 1) { *slot5 += 5 * v; n5 = 2; v = merged_marker; }
+                else { *slot5 += v; n5 = 0; v = merged_marker; }
                 break;
             case 3: v = quant_sym(c, e, 7); break;
             case 4:
                 v = quant_sym(c, e, 11);
                 if (n11 == 0) { slot11 = &q[ch][i]; v = 11 * v; n11 = 1; }
-                else { *slot11 += v; n11 = 0; v = 128; }
+                else { *slot11 += v; n11 = 0; v = merged_marker; }
                 break;
             case 5: v = quant_sym(c, e, 15); break;
             case 14: v = quant_asym(c, e, 14); break;
@@ -650,12 +666,13 @@ static void write_block(orc_ac3enc_t *s, bitw *w, int blk)
     for (ch = 0; ch < s->nch_all; ch++)                            /* emit :1460-1501 */
         for (i = 0; i < s->nb_coefs[ch]; i++) {
             int b = s->bap[blk][ch][i], v = q[ch][i];
+            if ((b == 1 || b == 2 || b == 4) && v == merged_marker && opener[ch][i]) __atomic_add_fetch(&dbg_collisions, 1, __ATOMIC_RELAXED);
             switch (b) {
             case 0: break;
-            case 1: if (v != 128) put(w, 5, v); break;
-            case 2: if (v != 128) put(w, 7, v); break;
+            case 1: if (v != merged_marker) put(w, 5, v); break;
+            case 2: if (v != merged_marker) put(w, 7, v); break;
             case 3: put(w, 3, v); break;
-            case 4: if (v != 128) put(w, 7, v); break;
+            case 4: if (v != merged_marker) put(w, 7, v); break;
             case 14: put(w, 14, v); break;
             case 15: put(w, 16, v); break;
             default: put(w, b - 1, v); break;

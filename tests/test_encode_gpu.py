@@ -154,6 +154,42 @@ def test_encode_second_generation_content(engine, kind):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("marker", [26, 60, 62, 120])
+@pytest.mark.parametrize("kind,frames", [("tones", 3), ("bursts", 3), ("noise", 1)])
+def test_grouped_code_equal_to_the_merged_marker_is_not_written(engine, kind, frames, marker):
+    """ac3enc marks the slots of merged group members with 128 and its second pass skips every slot that holds 128
+    (ac3enc.cpp:1375-1413, 1466-1480): an opener whose (out-of-contract, garbage) 16-bit code equals 128 is not written
+    and the rest of the block moves up by 5 or 7 bits.  Content that produces such a code is practically impossible to
+    make (12 000 negative-shift quantisations of second-generation material: none), so the mechanism is exercised with
+    the marker moved to a value ordinary codes take - the same knob in the oracle (orc_ac3enc_set_marker) and in the
+    engine (AC3MI_ENC_MARKER, read per launch): dozens of dropped fields per frame, byte-exact streams."""
+    import ctypes
+    import os
+    L = H.orc()
+    L.orc_ac3enc_set_marker.argtypes = [ctypes.c_int]
+    L.orc_ac3enc_debug_counts.argtypes = [ctypes.POINTER(ctypes.c_long)] * 2
+    pcm = [H.gen_pcm(frames, 6, seed=40 + s, kind=kind) for s in range(3 if frames > 1 else 7)]      # (one-frame streams: the unsplit pack kernel)
+    plain, _ = _oracle(pcm, 6, 384000)
+    c0 = ctypes.c_long()
+    L.orc_ac3enc_debug_counts(ctypes.byref(c0), None)
+    L.orc_ac3enc_set_marker(marker)
+    os.environ["AC3MI_ENC_MARKER"] = str(marker)
+    try:
+        want, _ = _oracle(pcm, 6, 384000)
+        got, _ = _gpu(engine, pcm, 6, 384000, taps=False)
+    finally:
+        L.orc_ac3enc_set_marker(128)
+        del os.environ["AC3MI_ENC_MARKER"]
+    c1 = ctypes.c_long()
+    L.orc_ac3enc_debug_counts(ctypes.byref(c1), None)
+    if c1.value == c0.value:
+        pytest.skip("this content has no code equal to %d" % marker)
+    assert not np.array_equal(want, plain)                                     # fields were dropped
+    assert np.array_equal(got, want), "bitstream differs in %d bytes" % int((got != want).sum())
+    again, _ = _gpu(engine, pcm, 6, 384000, taps=False)                       # and the default is back
+    assert np.array_equal(again, plain)
+
+
 @pytest.mark.parametrize("kind", ["silence", "rails", "impulses", "dc"])
 @pytest.mark.parametrize("nch,bitrate", [(6, 384000), (2, 192000), (1, 64000)])
 def test_encode_extreme_levels(engine, kind, nch, bitrate):
