@@ -77,6 +77,9 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
         const uint8_t *src = P.frames + fidx * P.frame_stride;
         float *cout = P.coef + fidx * 6 * P.n_in * 256;
         uint32_t status = 0;
+        // block 0 takes exponents, coupling or bit-allocation parameters the frame did not send (not a conforming frame):
+        // what it reuses is whatever the variant at hand has carried so far, so results may depend on the batch shape
+        bool reuse0 = false;
 
         // ---- stage the frame: byte-swapped dwords, zero padded ----
         {
@@ -199,11 +202,11 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                         for (int i = 0; i < nsub - 1; i++)
                             if (rd.get(1)) { st.cplbndstrc |= 1u << i; st.ncplbnd--; }
                     }
-                }
+                } else if (blk == 0) reuse0 = true;
                 if (st.chincpl) {                                           // coupling coordinates
                     int any = 0;
                     for (int i = 0; i < nf; i++)
-                        if ((st.chincpl >> i) & 1)
+                        if ((st.chincpl >> i) & 1) {
                             if (rd.get(1)) {
                                 const int master = 3 * rd.get(2);
                                 any = 1;
@@ -214,21 +217,29 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                                     const float co = (float)ma * sf_of(ex + master);
                                     if (lane == 0) L.cplco[i][j] = co;
                                 }
-                            }
+                            } else if (blk == 0) reuse0 = true;
+                        }
                     if (st.acmod == 2 && st.phsflginu && any)
                         for (int j = 0; j < st.ncplbnd; j++)
                             if (rd.get(1) && lane == 0) L.cplco[1][j] = -L.cplco[1][j];
                 }
-                if (st.acmod == 2 && rd.get(1)) {                           // rematstr
-                    const int end = st.chincpl ? st.cplstrtmant : 253;
-                    int i = 0;
-                    st.rematflg = 0;
-                    do st.rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                if (st.acmod == 2) {
+                    if (rd.get(1)) {                                        // rematstr
+                        const int end = st.chincpl ? st.cplstrtmant : 253;
+                        int i = 0;
+                        st.rematflg = 0;
+                        do st.rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                    } else if (blk == 0) reuse0 = true;
                 }
                 int cplexpstr = 0, lfeexpstr = 0, chexp = 0;   // chexp: 2 bits per channel
                 if (st.chincpl) cplexpstr = rd.get(2);
                 for (int i = 0; i < nf; i++) chexp |= rd.get(2) << (2 * i);
                 if (st.lfeon) lfeexpstr = rd.get(1);
+                if (blk == 0) {
+                    if (st.chincpl && !cplexpstr) reuse0 = true;
+                    if (st.lfeon && !lfeexpstr) reuse0 = true;
+                    for (int i = 0; i < nf; i++) if (!((chexp >> (2 * i)) & 3)) reuse0 = true;
+                }
 #pragma unroll
                 for (int i = 0; i < 5; i++)
                     if (i < nf && !err && ((chexp >> (2 * i)) & 3)) {
@@ -274,6 +285,7 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
 
                 // ---- bit-allocation parameters: parse.c:738-772 ----
                 if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
+                else if (blk == 0) reuse0 = true;
                 if (rd.get(1)) {
                     redo = 127;
                     st.csnroffst = rd.get(6);
@@ -281,11 +293,13 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
 #pragma unroll
                     for (int i = 0; i < 5; i++) if (i < nf) st.cbai[i] = rd.get(7);
                     if (st.lfeon) st.cbai[5] = rd.get(7);
-                }
-                if (st.chincpl && rd.get(1)) {
-                    redo |= 64;
-                    st.cplfleak = 9 - rd.get(3);
-                    st.cplsleak = 9 - rd.get(3);
+                } else if (blk == 0) reuse0 = true;
+                if (st.chincpl) {
+                    if (rd.get(1)) {
+                        redo |= 64;
+                        st.cplfleak = 9 - rd.get(3);
+                        st.cplsleak = 9 - rd.get(3);
+                    } else if (blk == 0) reuse0 = true;
                 }
                 if (rd.get(1)) {                                            // deltbaie
                     redo = 127;
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (MODE != 1 && lane == 0) P.status[fidx] = status;
+        if (MODE != 1 && lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
         if (MODE == 1 && lane == 0) P.frame_draws[fidx] = frame_draws;
     }
     if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;

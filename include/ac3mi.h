@@ -105,15 +105,24 @@ typedef struct {
  * d_lfsr 1, d_last 6*256 samples, d_csnroffst 1.  Pass NULL to return to "stream s uses entry s". */
 int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
 
-/* How ac3mi_decode_batch / ac3mi_transcode_batch spread the front end over the GPU (new; results are identical):
- *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame);
+/* How ac3mi_decode_batch / ac3mi_decode_s16_batch / ac3mi_transcode_batch spread the work over the GPU (new):
+ *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame),
+ *      coefficient planes go through HBM to the transform kernel;
  *   2  for few, long streams: a counting pass finds every frame's number of dither draws, a prefix pass the generator
- *      state each frame starts from, then one wavefront per frame decodes them all at once.  Relies on what the AC-3
- *      syntax guarantees: block 0 of a frame re-sends exponents, coupling and bit-allocation parameters;
- *   0  (default) choose by batch shape. */
+ *      state each frame starts from, then one wavefront per frame decodes them all at once;
+ *   3  one 512-thread workgroup per stream: a wavefront per channel beside a parser and a transformer wavefront, the
+ *      coefficient planes stay in LDS and the transform is fused in (a third of the latency of variant 1 per frame,
+ *      no plane traffic in HBM; ahead for batches of up to about 2 000 streams);
+ *   0  (default) choose by batch shape.
+ * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
+ * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and
+ * the fused and the separate transform execute the same arithmetic.  A frame whose block 0 reuses state it did not send
+ * (damaged or non-conforming) gets status bit AC3MI_STATUS_REUSE0 (0x200): variants 1 and 3 then continue from what the
+ * previous frame of the call left behind (as liba52 does), variant 2 from zeros - the result depends on the batch shape. */
+#define AC3MI_STATUS_REUSE0 0x200u
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 
-/* Workspace bound (new; results are identical).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
+/* Workspace bound (new; results do not depend on it, except for frames flagged AC3MI_STATUS_REUSE0 at a tile boundary).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
  * their intermediates (coefficient planes, MDCT coefficients, exponents, PCM between decoder and encoder: 37 / 60 /
  * 152 KB per frame) in workspaces owned by the context.  A batch of more than `frames` frames goes through in tiles
  * of whole streams of at most that many frames each (at least one stream), one after the other on the context's
@@ -191,11 +200,12 @@ int ac3mi_decode_planes(const ac3mi_decode_desc *desc, int *n_out, int *out_flag
  * d_pcm     [n_streams][frames_per_stream][6][n_out][256] float, a52_samples() plane order
  * d_status  [n_streams][frames_per_stream]: bit b (0..5) = a52_block b returned 1 (that block and
  *           the rest of the frame are silence), bit 8 = a52_syncinfo/a52_frame refused the frame,
- *           bits 16..23 = output flags a52_frame granted
+ *           bit 9 (AC3MI_STATUS_REUSE0) = block 0 reused state the frame did not send, bits 16..23 = output
+ *           flags a52_frame granted
  * Across frames only d_delay and d_lfsr matter for a valid stream (block 0 of every AC-3 frame re-sends
  * exponents, coupling and bit-allocation parameters), and only they persist across calls.  Inside one call
- * the serial front end (ac3mi_set_decode_mode 1) additionally carries exponent / bit-allocation / coupling
- * state from frame to frame exactly as a52_state_s does, which only shows on streams that break that rule;
+ * the serial variants (ac3mi_set_decode_mode 1 and 3) additionally carry exponent / bit-allocation / coupling
+ * state from frame to frame as a52_state_s does, which only shows on frames flagged AC3MI_STATUS_REUSE0;
  * the frame-parallel front end (mode 2, chosen automatically for few long streams) starts every frame clean.
  */
 int ac3mi_decode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint8_t *d_frames,

@@ -167,3 +167,35 @@ def test_wg_persistent_grid_many_streams(wg_engine):
         for b in range(6):
             L.orc_convert_s16(H.P(np.ascontiguousarray(ref384[0, f, b]), H.fp), H.P(ref16, H.i16p), oflags)
             assert int(np.abs(g[0, f, b].astype(np.int32) - ref16.astype(np.int32)).max()) <= 1
+
+
+def test_status_flags_frames_whose_block_0_reuses_unsent_state(wg_engine):
+    """AC3MI_STATUS_REUSE0: a frame whose first block says "reuse" for exponents / coupling / bit-allocation parameters
+    it never sent is decoded from whatever state the variant has carried (include/ac3mi.h).  Damaged one-frame streams
+    start from a clean state in every variant, so here the variants still agree bit for bit - and they agree on the flag."""
+    import torch
+    from tests import fuzz_corrupt
+    pkg = H.pkg()
+    acmod, lfe = 7, 1
+    frames, _, want_fail, want_foreign, _ = fuzz_corrupt.make_damaged(21, acmod, lfe, S=160)
+    S, fb = frames.shape
+    stride = (fb + 3) & ~3
+    padded = np.zeros((S, 1, stride), np.uint8)
+    padded[:, 0, :fb] = frames
+    desc = pkg.DecodeDesc(flags=7 | 16, level=1.0, bias=0.0, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
+    res = {}
+    for mode in (1, 3):
+        wg_engine.set_decode_mode(mode)
+        delay = torch.zeros((S, 6, 128), dtype=torch.float32, device="cuda")
+        lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+        pcm, status, taps = wg_engine.decode_batch(desc, torch.from_numpy(padded).cuda(), delay, lfsr, taps=True)
+        wg_engine.sync()
+        res[mode] = (status.cpu().numpy()[:, 0], taps["coef"].cpu().numpy(), pcm.cpu().numpy(), lfsr.cpu().numpy())
+    a, b = res[1], res[3]
+    assert np.array_equal(a[0], b[0]), np.nonzero(a[0] != b[0])
+    assert np.array_equal(a[3], b[3])
+    ok = (a[0] & 0x13f) == 0                                  # frames both variants decoded completely
+    assert np.array_equal(a[1][ok].view(np.uint32), b[1][ok].view(np.uint32))
+    assert np.array_equal(a[2][ok].view(np.uint32), b[2][ok].view(np.uint32))
+    flagged = (a[0] & 0x200) != 0
+    assert flagged.any() and not flagged[:6].any()           # some damaged frames, never the undamaged controls
