@@ -18,6 +18,7 @@ struct DecTables {
     // dequantised value of member m of a code: 3-level [code*3+m] at 0 (32 codes), 5-level at 96 (128 codes),
     // 11-level [code*2+m] at 480 (128 codes), 7-level [code] at 736, 15-level [code] at 744; reserved codes give 0
     float qtab[760];
+    uint32_t desc[128];     // per row byte of the bap rows: see mant_desc (decode_common.h)
 };
 
 // encoder tables (device copy): ENC/ac3tab.h + the runtime tables of AC3_encode_init

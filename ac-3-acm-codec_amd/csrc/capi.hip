@@ -51,6 +51,16 @@ void build_host_tables(float *window, float2 *tw_long, float2 *tw_short)
 }
 
 // decoder tables: L52/bit_allocate.c:31-101, L52/tables.h:49-246
+// descriptor of a row byte (same function as decode_common.h's mant_desc, host copy)
+static uint32_t mant_desc_host(uint32_t b)
+{
+    const uint32_t k1 = b >> 5, nbp = b & 31u;
+    const uint32_t qbase = k1 == 1 ? 0u : k1 == 2 ? 96u : k1 == 3 ? 480u : nbp == 3 ? 736u : nbp == 4 ? 744u : 0u;
+    const uint32_t per = k1 == 3 ? 2u : k1 ? 3u : 0u, obits = k1 == 1 ? 5u : k1 ? 7u : 0u;
+    const uint32_t coded = (k1 || nbp == 3 || nbp == 4) ? 1u : 0u;
+    return qbase | (per << 10) | (obits << 12) | (coded << 15);
+}
+
 void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
 {
     uint8_t la[256];
@@ -92,6 +102,7 @@ void build_dec_tables(DecTables *t, uint16_t *lfsr_seq, uint16_t *lfsr_idx)
     }
     for (int code = 0; code < 7; code++) t->qtab[736 + code] = t->qlev[8 + code];
     for (int code = 0; code < 15; code++) t->qtab[744 + code] = t->qlev[27 + code];
+    for (int b = 0; b < 128; b++) t->desc[b] = mant_desc_host((uint32_t)b);
     // dither generator (L52/parse.c:310-319, table L52/tables.h:213-246): one call advances a
     // 16-bit Galois LFSR (feedback 0xa011) by 8 steps.  It is GF(2)-linear with period 65535,
     // so the sequence from state 1 plus its inverse index give O(1) access to any later draw.

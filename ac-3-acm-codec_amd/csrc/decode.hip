@@ -30,8 +30,11 @@ namespace ac3mi {
 // stream (block 0 re-sends exponents, coupling and bit-allocation parameters), so a counting pass (MODE 1: one
 // wavefront per frame, everything but the mantissa values) finds each frame's number of dither draws, a prefix pass
 // turns them into the LFSR state every frame starts from, and MODE 2 decodes all frames at once.
+#ifndef DEC_LB
+#define DEC_LB 5
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
+__global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P)
 {
     __shared__ DecLDS L;
     extern __shared__ uint32_t frw[];
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
     // ---- constant tables into LDS ----
     for (int i = lane; i < 256; i += 64) L.la_neg[i] = P.tab->la_neg[i];
     if (lane < 50) L.hth[lane] = 0;
-    L.width[lane] = P.tab->width[lane];
+    L.width[lane] = remap_width(P.tab->width[lane]);        // row bytes: see decode_common.h, mantissa stage
+    for (int i = lane; i < 100; i += 64) L.desc[i] = mant_desc((uint32_t)i);
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
     for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
     for (int i = lane; i < ROWS; i += 64) { L.exp[i] = 0; L.bap[i] = 0; }
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
         {
             const int nw = (P.frame_bytes + 3) >> 2;
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-            for (int i = lane; i < nw + 4; i += 64) {
+            for (int i = lane; i < nw + 6; i += 64) {             // (the mantissa stage reads three dwords from index <= nw + 2)
                 uint32_t v = 0;
                 if (i < nw) {
                     v = s32[i];
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                     for (int i = lane; i < 256; i += 64) {
                         const bool in = c != 5 || i < LFE_ROW;
                         te[c * 256 + i] = in ? L.exp[row_off(c) + i] : 0;
-                        tb[c * 256 + i] = in ? L.bap[row_off(c) + i] : 0;
+                        tb[c * 256 + i] = in ? unmap_width(L.bap[row_off(c) + i]) : 0;
                     }
             }
 
@@ -411,169 +415,133 @@ __global__ __launch_bounds__(64, 6) void decode_kernel(const DecodeParams P)
                 // ---- gains: parse.c:810-811 ----
                 a52_downmix_coeff_hd(gain, st.acmod, st.output, st.dynrng, st.clev, st.slev);
 
-                // ---- mantissa stream segments (parse.c:813-879 order) ----
-                int nseg = 0, total = 0, cpl_done = 0;
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    if (i >= nf) continue;
-                    if (lane == 0) { L.seg_ch[nseg] = (uint8_t)i; L.seg_start[nseg] = 0; L.seg_base[nseg] = (int16_t)total; }
-                    nseg++; total += st.endmant[i];
-                    if (((st.chincpl >> i) & 1) && !cpl_done) {
-                        cpl_done = 1;
-                        if (lane == 0) { L.seg_ch[nseg] = 6; L.seg_start[nseg] = (uint8_t)st.cplstrtmant; L.seg_base[nseg] = (int16_t)total; }
-                        nseg++; total += st.cplendmant - st.cplstrtmant;
-                    }
+                // ---- mantissas: the segments of the block in bitstream order (parse.c:813-879: channel 0, the coupling
+                //      channel right after the first coupled channel, ..., LFE last), one step of four bins per lane each
+                //      (mant_first_half / mant_value, decode_common.h).  Ranks of the grouped codes, bit offsets and dither
+                //      draw indices run on from segment to segment; planes go straight to HBM, 16 bytes per lane. ----
+                if (st.chincpl && lane < 18) {                              // sub-band -> band (parse.c:448-456)
+                    const uint32_t below = st.cplbndstrc & ((1u << lane) - 1u);
+                    L.cplbnd[lane] = (uint8_t)(lane - __popc(below));
                 }
-                if (st.lfeon) {
-                    if (lane == 0) { L.seg_ch[nseg] = 5; L.seg_start[nseg] = 0; L.seg_base[nseg] = (int16_t)total; }
-                    nseg++; total += 7;
-                }
-                if (lane == 0) L.seg_base[nseg] = (int16_t)total;
-                if (st.chincpl && lane == 0) {                              // sub-band -> band (parse.c:448-456)
-                    uint32_t strc = st.cplbndstrc;
-                    int bnd = 0, nsub = (st.cplendmant - st.cplstrtmant) / 12;
-                    for (int sb = 0; sb < nsub; sb++) {
-                        L.cplbnd[sb] = (uint8_t)bnd;
-                        if (!(strc & 1)) bnd++;
-                        strc >>= 1;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
                 const int ncpl_dith = __popc(st.chincpl & dithmask);
                 const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
                 const bool lfsr_live = st.lfsr != 0;
-
-                // One pass, 64 consecutive coefficients of a segment per step.  Two packed wavefront
-                // scans per step: grouped-code ranks (who opens a 5/7-bit code), then bit offsets and
-                // dither draw indices.  The lane that opens a code publishes it in L.gcode for the
-                // one or two members that follow (same step or a later one; groups run across
-                // channels: parse.c:815).
-                uint32_t bitbase = rd.pos;
-                int b3 = 0, b5 = 0, b11 = 0, dbase = 0;
                 const int remat_end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
+                const int cplfirst = st.chincpl ? __builtin_ctz(st.chincpl) : 99;
+                const int nseg = nf + (st.chincpl ? 1 : 0) + (st.lfeon ? 1 : 0);
+                SegBase sb;
+                sb.bit = rd.pos;
+                sb.r3 = sb.r5 = sb.r11 = sb.draw = 0;
                 for (int k = 0; k < nseg; k++) {
-                    const int ch = (int)rfl(L.seg_ch[k]), start = (int)rfl(L.seg_start[k]);
-                    const int len = (int)rfl((uint32_t)(L.seg_base[k + 1] - L.seg_base[k]));
+                    // segment k -> slot (0..4 fbw, 5 lfe, 6 coupling channel)
+                    int slot;
+                    if (st.chincpl) slot = k <= cplfirst ? k : k == cplfirst + 1 ? 6 : k - 1 < nf ? k - 1 : 5;
+                    else slot = k < nf ? k : 5;
+                    int start = 0, end, draws = 0;
                     float g = 0.f;
-                    int draws = 0;
-                    const bool remat1 = ch == 1 && st.acmod == 2 && st.rematflg != 0;
-                    if (ch < 5) {
-                        g = ch == 0 ? gain[0] : ch == 1 ? gain[1] : ch == 2 ? gain[2] : ch == 3 ? gain[3] : gain[4];
-                        draws = (dithmask >> ch) & 1;
-                    } else if (ch == 5) {
+                    if (slot < 5) {
+                        end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2] : slot == 3 ? st.endmant[3] : st.endmant[4];
+                        g = slot == 0 ? gain[0] : slot == 1 ? gain[1] : slot == 2 ? gain[2] : slot == 3 ? gain[3] : gain[4];
+                        draws = (dithmask >> slot) & 1;
+                    } else if (slot == 5) {
+                        end = 7;
                         g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
                     } else {
+                        start = st.cplstrtmant;
+                        end = st.cplendmant;
                         draws = ncpl_dith;
                     }
-                    for (int i0 = 0; i0 < len; i0 += 64) {
-                        const bool act = i0 + lane < len;
-                        const int bin = start + (act ? i0 + lane : 0);
-                        const int w = act ? (int)L.bap[row_off(ch) + bin] : -9;
-                        const int e = L.exp[row_off(ch) + bin];
-                        const int kind = w == -1 ? 0 : w == -2 ? 1 : w == -3 ? 2 : -1;
-                        const uint32_t gcnt = kind < 0 ? 0u : 1u << (8 * kind);
-                        const uint32_t gincl = wave_incl_scan_u32(gcnt);
-                        const uint32_t gexcl = gincl - gcnt;
-                        const int rank = kind == 0 ? b3 + (int)(gexcl & 255u)
-                                       : kind == 1 ? b5 + (int)((gexcl >> 8) & 255u)
-                                                   : b11 + (int)(gexcl >> 16);
-                        const int per = kind == 2 ? 2 : 3;
-                        const int grp = kind == 2 ? rank >> 1 : (int)(((uint32_t)rank * 0xaaabu) >> 17);      // rank / 3, rank < 2^15
-                        const int mem = rank - grp * per;
-                        const bool opens = kind >= 0 && mem == 0;
-                        const int nb = w > 0 ? w : opens ? (kind == 0 ? 5 : 7) : 0;
-                        const int nd = w == 0 ? draws : 0;
-                        const uint32_t bcnt = (uint32_t)nb | ((uint32_t)nd << 16);
-                        const uint32_t bincl = wave_incl_scan_u32(bcnt);
-                        const uint32_t off = bitbase + (bincl & 0xffffu) - (uint32_t)nb;
-                        int cd = dbase + (int)(bincl >> 16) - nd;
-                        const uint32_t gtot = wave_last(gincl), btot = wave_last(bincl);
-
-                        if (MODE == 1) {                             // counting pass: ranks, bit offsets and draw counts only
-                            b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
-                            bitbase += btot & 0xffffu;
-                            dbase += (int)(btot >> 16);
-                            continue;
+                    sb.mult = draws;
+                    BinRegs R;
+                    const SegTotals T = mant_first_half<GRING, GRING - 1, MODE == 1>(L.exp + row_off(slot), L.bap + row_off(slot), L.desc, L.gcode, frw,
+                                                                                    FB.last, start, end, slot == 5 ? LFE_ROW / 4 : 64, sb, R, lane);
+                    sb.bit += T.bits;
+                    sb.r3 += T.n3;
+                    sb.r5 += T.n5;
+                    sb.r11 += T.n11;
+                    sb.draw += T.draws;
+                    if (MODE == 1) continue;                         // counting pass: ranks, bit offsets and draw counts only
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (slot < 6) {
+                        float out[4];
+                        int cd = R.cd;
+                        const bool dith = draws != 0 && lfsr_live;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int bin = 4 * lane + j;
+                            const bool zero = bin < end && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
+                            const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
+                            float q = mant_value<GRING, GRING - 1>(R, j, L.desc, L.gcode, P.tab->qtab);
+                            if (dith && __any(zero)) {                // wave-uniform: no table access when no lane draws
+                                const float dv = (float)dither_value(P, lfsr_i0, cd);
+                                q = zero ? dv : q;
+                            }
+                            cd += (zero && draws) ? 1 : 0;
+                            out[j] = q * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
                         }
-                        uint32_t raw = 0;
-                        if (nb) raw = peek(FB, off, nb);
-                        const int gslot = kind == 2 ? 64 + (grp & 63) : (kind == 1 ? 32 : 0) + (grp & 31);
-                        if (opens) L.gcode[gslot] = (uint8_t)raw;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-                        // 3/5/11-level codes (3/3/2 members) and the 7- and 15-level codes of bap 3 and 4 through one
-                        // table (reserved codes read 0); wider mantissas are two's complement fractions
-                        float q = 0.f;
-                        {
-                            const bool coded = kind >= 0 || w == 3 || w == 4;
-                            const int code = kind >= 0 ? (int)L.gcode[gslot] : (int)raw;
-                            const int base = kind == 0 ? 0 : kind == 1 ? 96 : kind == 2 ? 480 : w == 3 ? 736 : 744;
-                            const int ti = base + code * (kind >= 0 ? per : 1) + (kind >= 0 ? mem : 0);
-                            const float tv = (float)P.tab->qtab[coded ? ti : 0];
-                            const float pv = (float)((((int32_t)(raw << ((32 - w) & 31))) >> ((32 - w) & 31)) * (1 << ((16 - w) & 31)));
-                            q = coded ? tv : w > 0 ? pv : 0.f;
-                        }
-
-                        if (ch < 6) {
-                            if (w == 0 && draws) q = (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0);
-                            float v = q * (sf_of(e) * g);
-                            float *dst = cblk + (ch == 5 ? 0 : ch + in_lfe) * 256 + bin;
-                            if (remat1 && act && bin >= 13 && bin < remat_end) {
-                                // rematrix: parse.c:837-865.  Channel 0's bin was stored by this same lane.
+                        float *plane = cblk + (slot == 5 ? 0 : slot + in_lfe) * 256;
+                        if (slot == 1 && st.acmod == 2 && st.rematflg != 0) {
+                            // rematrix: parse.c:837-865.  Channel 0's bins were stored by this same lane.
+                            float4 a4 = *reinterpret_cast<const float4 *>(plane - 256 + 4 * lane);
+                            float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int bin = 4 * lane + j;
                                 const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
-                                if ((st.rematflg >> band) & 1) {
-                                    const float a = dst[-256];
-                                    dst[-256] = a + v;
-                                    v = a - v;
+                                if (bin >= 13 && bin < remat_end && ((st.rematflg >> band) & 1)) {
+                                    const float x = a[j], v = out[j];
+                                    a[j] = x + v;
+                                    out[j] = x - v;
                                 }
                             }
-                            if (act) *dst = v;
+                            *reinterpret_cast<float4 *>(plane - 256 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+                        }
+                        if (slot < 5 && ((st.chincpl >> slot) & 1)) {
+                            // a coupled channel: its own bins, zeros up to the coupling range (a damaged frame can leave a gap
+                            // there: liba52 then keeps the previous block's PCM, its buffer being transformed in place; here
+                            // zeros) and from its end on; the coupling channel's share in between is written by that segment
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int bin = 4 * lane + j;
+                                if (bin < end || bin < st.cplstrtmant || bin >= st.cplendmant) plane[bin] = out[j];
+                            }
                         } else {
-                            // coupling channel: parse.c:435-556
-                            const int bnd = L.cplbnd[(bin - st.cplstrtmant) / 12];
-                            const float m = q * sf_of(e);
+                            *reinterpret_cast<float4 *>(plane + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
+                        }
+                    } else {
+                        // coupling channel: parse.c:435-556
+                        int cd = R.cd;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int bin = 4 * lane + j;
+                            const bool in = bin >= start && bin < end;
+                            const bool zero = in && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
+                            const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
+                            const float m = mant_value<GRING, GRING - 1>(R, j, L.desc, L.gcode, P.tab->qtab) * sf_of(e);
+                            const int bnd = L.cplbnd[in ? (bin - start) / 12 : 0];
+                            int cdc = cd;
                             for (int c = 0; c < nf; c++) {
                                 if (!((st.chincpl >> c) & 1)) continue;
                                 const float gc = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
                                 const float co = L.cplco[c][bnd] * gc;
                                 float v = m * co;
-                                if (w == 0) {
+                                if (zero) {
                                     v = 0.f;
-                                    if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cd) : 0); cd++; }
+                                    if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cdc) : 0); cdc++; }
                                 }
-                                if (act) cblk[(c + in_lfe) * 256 + bin] = v;
+                                if (in) cblk[(c + in_lfe) * 256 + bin] = v;
                             }
+                            cd += zero ? draws : 0;
                         }
-                        b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
-                        bitbase += btot & 0xffffu;
-                        dbase += (int)(btot >> 16);
                     }
                 }
-                rd.pos = bitbase;
-                const int nd_total = dbase;
+                rd.pos = sb.bit;
+                const int nd_total = sb.draw;
                 frame_draws += (uint32_t)nd_total;
                 // advance the dither generator past this block's draws
                 if (MODE != 1 && lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
-                if (MODE == 1) continue;                             // no planes in the counting pass
-
-                // zero tails: parse.c:828-834, 871-872
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    if (c >= nf) continue;
-                    const int from = ((st.chincpl >> c) & 1) ? st.cplendmant : st.endmant[c];
-                    for (int i = from + lane; i < 256; i += 64) cblk[(c + in_lfe) * 256 + i] = 0.f;
-                    // a damaged frame can move the coupling region away from a channel that reuses its exponents:
-                    // liba52 then leaves the previous block's PCM in [endmant, cplstrtmant) (its buffer is transformed
-                    // in place); here those bins are zero
-                    if (((st.chincpl >> c) & 1) && st.endmant[c] < st.cplstrtmant)
-                        for (int i = st.endmant[c] + lane; i < st.cplstrtmant; i += 64) cblk[(c + in_lfe) * 256 + i] = 0.f;
-                }
-                if (st.lfeon) for (int i = 7 + lane; i < 256; i += 64) cblk[i] = 0.f;
             }
 
             // ---- a failed block leaves zero planes ----
@@ -645,7 +613,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     P.frame_draws = L.frame_draws;
     P.frame_lfsr = L.frame_lfsr;
     static const int lds_pad = getenv("AC3MI_DEC_LDS_PAD") ? atoi(getenv("AC3MI_DEC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
-    const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 4) * 4 + lds_pad;
+    const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + lds_pad;
     if (!L.frame_parallel) {
         hipLaunchKernelGGL(decode_kernel<0>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
         return hipGetLastError();

@@ -13,6 +13,7 @@ constexpr int ROW = 260;                  // exp/bap row pitch (bytes): 65 dword
 // last; with the dequantiser table read through L1 the wavefront's LDS is 6.5 KB = 24 wavefronts per CU, what the
 // 80 VGPRs of __launch_bounds__(64, 6) allow (the kernel is latency-bound, occupancy pays).
 constexpr int LFE_ROW = 68;
+constexpr int GRING = 128;                // see DecLDS::gcode
 constexpr int ROWS = 6 * ROW + LFE_ROW;
 __device__ __forceinline__ int row_off(int slot) { return slot < 5 ? slot * ROW : slot == 6 ? 5 * ROW : 6 * ROW; }
 
@@ -32,21 +33,20 @@ struct DecLDS {
     int8_t bap[ROWS];
     int8_t deltba[6][52];                 // 0..4 fbw, 5 = cpl
     float cplco[5][18];
-    uint8_t gcode[128];                   // open 3/5/11-level codes: rings of 32 / 32 / 64 (a step opens <= 22 / 22 / 32)
+    uint8_t gcode[3 * 128 + 4];           // open 3/5/11-level codes: a ring of GRING groups per kind (a segment opens < 128), then the sink
     uint8_t cplbnd[20];                   // coupling sub-band -> band
-    int16_t seg_base[9];                  // mantissa stream segments
-    uint8_t seg_ch[8], seg_start[8];
     int8_t la_neg[256];
     uint16_t hth[50];
     int8_t width[64];
     uint8_t band_end[30];
     uint8_t band_of_bin[256];
     int16_t bmask[52];                    // per-band mask of the channel being allocated
+    uint32_t desc[100];                   // mant_desc of the row bytes 0..96
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// the staged frame: byte-swapped dwords in dynamic LDS, frame_bytes/4 (rounded up) + 4 zero words
+// the staged frame: byte-swapped dwords in dynamic LDS, frame_bytes/4 (rounded up) + 6 zero words
 struct FrameBits {
     const uint32_t *w;
     uint32_t last;          // highest index a 2-dword read may start at
@@ -368,6 +368,138 @@ __device__ __forceinline__ int16_t dither_value(const DecodeParams &P, uint32_t 
     i %= 65535u;
     const int16_t ns = (int16_t)P.lfsr_seq[i];
     return (int16_t)((3 * ns) >> 2);
+}
+
+
+// ---------------------------------------------------------------------------
+// The mantissa stage shared by both front ends, four bins per lane, branch-free (L52/parse.c:336-433 coeff_get).
+//
+// Row bytes (the bap rows in LDS): 0 = no bits, 3..16 = that many plain bits, 32 / 64 / 96 = member of a 3- / 5- /
+// 11-level code (ba_width's -1 / -2 / -3, remapped when the width table is staged: remap_width), so that
+// plain bits = b & 31 and kind = b >> 5.  The per-code constants come from a 128-entry descriptor table (mant_desc).
+
+__device__ __forceinline__ int8_t remap_width(int w) { return (int8_t)(w >= 0 ? w : -32 * w); }
+__device__ __forceinline__ int8_t unmap_width(int b) { return (int8_t)(b >= 32 ? -(b >> 5) : b); }      // liba52's form, for the taps
+
+// descriptor of a row byte: dequantiser table base | members per code << 10 | opener bits << 12 | coded << 15
+__host__ __device__ inline uint32_t mant_desc(uint32_t b)
+{
+    const uint32_t k1 = b >> 5, nbp = b & 31u;
+    const uint32_t qbase = k1 == 1 ? 0u : k1 == 2 ? 96u : k1 == 3 ? 480u : nbp == 3 ? 736u : nbp == 4 ? 744u : 0u;
+    const uint32_t per = k1 == 3 ? 2u : k1 ? 3u : 0u, obits = k1 == 1 ? 5u : k1 ? 7u : 0u;
+    const uint32_t coded = (k1 || nbp == 3 || nbp == 4) ? 1u : 0u;
+    return qbase | (per << 10) | (obits << 12) | (coded << 15);
+}
+
+// where a segment's mantissas start
+struct SegBase {
+    uint32_t bit;           // first bit of the segment
+    int r3, r5, r11;        // 3/5/11-level mantissas of the block before the segment (global ranks)
+    int draw;               // dither draws of the block before the segment
+    int mult;               // draws per zero-bit bin of the segment
+    uint32_t total_bits;    // of the block (decode_wg.hip's prefix only)
+    int total_draws;
+};
+struct SegTotals {
+    uint32_t bits;
+    int n3, n5, n11, draws;
+};
+
+// registers kept from the first to the second half of the stage for the lane's 4 bins
+struct BinRegs {
+    uint32_t raw[4];
+    uint32_t bap4, exp4;    // row bytes (bins outside the segment zeroed) and exponents
+    uint32_t gm[4];         // group | member << 12
+    int cd;                 // draw index of the lane's first zero-bit bin
+};
+
+// First half: ranks, bit offsets, field extraction; openers publish their codes in gcode[(kind-1)*GCN + (group & GMASK)]
+// (gcode[3*GCN] is a sink for lanes that open nothing).  COUNT: offsets and totals only.  `lanes4` = lanes that may read
+// their row dword (the short LFE row).
+template <int GCN, int GMASK, bool COUNT>
+__device__ __forceinline__ SegTotals mant_first_half(const uint8_t *erow, const int8_t *brow, const uint32_t *desc, uint8_t *gcode,
+                                                     const uint32_t *frw, uint32_t frw_last, int start, int end, int lanes4,
+                                                     const SegBase &sb, BinRegs &R, int lane)
+{
+    const bool have = lane < lanes4;
+    const uint32_t bap4 = have ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
+    R.exp4 = have ? *reinterpret_cast<const uint32_t *>(erow + 4 * lane) : 0u;
+    uint32_t b[4], d[4], inc[4], zero[4];
+    uint32_t gl = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int bin = 4 * lane + j;
+        const uint32_t act = (uint32_t)(bin >= start) & (uint32_t)(bin < end);
+        b[j] = ((bap4 >> (8 * j)) & 0xffu) * act;
+        zero[j] = act & (uint32_t)(b[j] == 0u);
+        d[j] = desc[b[j]];
+        inc[j] = (1u << (30u - 10u * (b[j] >> 5))) & 0x3fffffffu;      // 1 in the 10-bit field of the bin's kind (3-level: bits 20-29, 5-level: 10-19, 11-level: 0-9), 0 for plain bins
+        gl += inc[j];
+    }
+    R.bap4 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    const uint32_t gin = wave_incl_scan_u32(gl), gex = gin - gl;
+    // phase of each kind at the start of the segment and the group its first member belongs to
+    const int q3 = (int)(((uint32_t)sb.r3 * 0xaaabu) >> 17), q5 = (int)(((uint32_t)sb.r5 * 0xaaabu) >> 17), q11 = sb.r11 >> 1;
+    uint32_t run = gex + ((uint32_t)(sb.r3 - 3 * q3) << 20) + ((uint32_t)(sb.r5 - 3 * q5) << 10) + (uint32_t)(sb.r11 & 1);
+    uint32_t nb[4];
+    uint32_t nbsum = 0, ndsum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t k1 = b[j] >> 5;
+        const uint32_t x = (run >> (30u - 10u * k1)) & 0x3ffu;        // phase + rank inside the segment (0 for plain bins: bits 30, 31)
+        const uint32_t two = (uint32_t)(k1 == 3u);
+        const uint32_t q = two ? x >> 1 : (x * 171u) >> 9;            // x / members per code, x < 256 + 3
+        const uint32_t mem = x - q * (3u - two);
+        const uint32_t opens = (uint32_t)(k1 != 0u) & (uint32_t)(mem == 0u);
+        nb[j] = (b[j] & 31u) + opens * ((d[j] >> 12) & 7u);
+        const uint32_t gbase = k1 == 1u ? (uint32_t)q3 : k1 == 2u ? (uint32_t)q5 : (uint32_t)q11;
+        R.gm[j] = (gbase + q) | (mem << 12);
+        run += inc[j];
+        nbsum += nb[j];
+        ndsum += zero[j] * (uint32_t)sb.mult;
+        // the opener publishes its code where the other members will look for it; everybody else writes to the sink
+        zero[j] = opens ? (k1 - 1u) * GCN + ((gbase + q) & (uint32_t)GMASK) : 3u * GCN;      // (zero[] reused: gcode slot)
+    }
+    const uint32_t bl = nbsum | (ndsum << 16);
+    const uint32_t bin_ = wave_incl_scan_u32(bl);
+    const uint32_t gtot = wave_last(gin), btot = wave_last(bin_);
+    SegTotals T;
+    T.bits = btot & 0xffffu;
+    T.draws = (int)(btot >> 16);
+    T.n3 = (int)((gtot >> 20) & 0x3ffu);
+    T.n5 = (int)((gtot >> 10) & 0x3ffu);
+    T.n11 = (int)(gtot & 0x3ffu);
+    R.cd = sb.draw + (int)(bin_ >> 16) - (int)ndsum;
+    if (COUNT) return T;
+    const uint32_t off = sb.bit + (bin_ & 0xffffu) - nbsum;
+    // the lane's fields are at most 64 consecutive bits starting at `off`: a 64-bit window out of three dwords
+    uint32_t wi = off >> 5;
+    wi = wi < frw_last ? wi : frw_last;
+    const uint32_t d0 = frw[wi], d1 = frw[wi + 1], d2 = frw[wi + 2];
+    const uint32_t k = off & 31u;
+    uint64_t win = ((((uint64_t)d0 << 32) | d1) << k) | (uint64_t)((d2 >> 1) >> (31u - k));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        R.raw[j] = ((uint32_t)(win >> 32) >> 1) >> (31u - nb[j]);       // top nb bits (0 for nb = 0)
+        win <<= nb[j];
+        gcode[zero[j]] = (uint8_t)R.raw[j];
+    }
+    return T;
+}
+
+// dequantised value of bin j before the exponent / gain scale (0 for a zero-bit bin)
+template <int GCN, int GMASK>
+__device__ __forceinline__ float mant_value(const BinRegs &R, int j, const uint32_t *desc, const uint8_t *gcode, const float *qtab)
+{
+    const uint32_t b = (R.bap4 >> (8 * j)) & 0xffu, k1 = b >> 5, nbp = b & 31u;
+    const uint32_t d = desc[b];
+    const uint32_t grp = R.gm[j] & 0xfffu, mem = R.gm[j] >> 12;
+    const uint32_t code = gcode[k1 ? (k1 - 1u) * GCN + (grp & (uint32_t)GMASK) : 3u * GCN];
+    const uint32_t coded = (d >> 15) & 1u;
+    const uint32_t qi = (d & 0x3ffu) + (k1 ? code * ((d >> 10) & 3u) + mem : R.raw[j]);
+    const float tv = qtab[coded ? qi : 0u];
+    const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
+    return coded ? tv : pv;
 }
 
 }  // namespace ac3mi

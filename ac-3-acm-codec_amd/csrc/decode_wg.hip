@@ -583,15 +583,6 @@ __device__ __forceinline__ void slot_census(WgLDS &L, int slot, int start, int e
 
 // where a slot's mantissas start: prefix over the segments of the block in bitstream order (parse.c:813-879: channel 0,
 // the coupling channel right after the first coupled channel, ..., LFE last).  One lane per segment.
-struct SegBase {
-    uint32_t bit;           // first bit of the segment
-    int r3, r5, r11;        // 3/5/11-level mantissas of the block before the segment (global ranks)
-    int draw;               // dither draws of the block before the segment
-    int mult;               // draws per zero-bit bin of the segment
-    uint32_t total_bits;    // of the block
-    int total_draws;
-};
-
 __device__ __forceinline__ int openers(int phase, int n, int per)     // members r in [phase, phase + n) with r % per == 0
 {
     return (phase + n + per - 1) / per - (phase + per - 1) / per;
@@ -642,89 +633,13 @@ __device__ SegBase segment_prefix(const WgLDS &L, const BlkInfo &B, int slot, in
     return r;
 }
 
-// registers a channel wave keeps from T2a to T2b for its 4 bins
-struct BinRegs {
-    uint32_t raw[4];
-    uint32_t bap4, exp4;    // row bytes (inactive bins zeroed) and exponents
-    uint32_t gm[4];         // group | member << 12
-    int cd;                 // draw index of the lane's first zero-bit bin
-};
-
 __device__ __forceinline__ void slot_t2a(WgLDS &L, const FrameBits FB, const uint32_t *frw, int slot, int start, int end, const SegBase &sb,
                                          BinRegs &R, int lane)
 {
-    const uint8_t *erow = L.exp + row_off(slot);
-    const int8_t *brow = L.bap + row_off(slot);
-    const bool have = slot != 5 || lane < LFE_ROW / 4;
-    uint32_t bap4 = have ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
-    R.exp4 = have ? *reinterpret_cast<const uint32_t *>(erow + 4 * lane) : 0u;
-    uint32_t b[4], d[4], inc[4], zero[4];
-    uint32_t gl = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int bin = 4 * lane + j;
-        const uint32_t act = (uint32_t)(bin >= start) & (uint32_t)(bin < end);
-        b[j] = ((bap4 >> (8 * j)) & 0xffu) * act;
-        zero[j] = act & (uint32_t)(b[j] == 0u);
-        d[j] = L.desc[b[j]];
-        inc[j] = (1u << (30u - 10u * (b[j] >> 5))) & 0x3fffffffu;      // 1 in the 10-bit field of the bin's kind (3-level: bits 20-29, 5-level: 10-19, 11-level: 0-9), 0 for plain bins
-        gl += inc[j];
-    }
-    R.bap4 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    const uint32_t gex = wave_incl_scan_u32(gl) - gl;
-    // phase of each kind at the start of the segment and the group its first member belongs to
-    const int q3 = (int)(((uint32_t)sb.r3 * 0xaaabu) >> 17), q5 = (int)(((uint32_t)sb.r5 * 0xaaabu) >> 17), q11 = sb.r11 >> 1;
-    uint32_t run = gex + ((uint32_t)(sb.r3 - 3 * q3) << 20) + ((uint32_t)(sb.r5 - 3 * q5) << 10) + (uint32_t)(sb.r11 & 1);
-    uint32_t nb[4];
-    uint32_t nbsum = 0, ndsum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t k1 = b[j] >> 5;
-        const uint32_t x = (run >> (30u - 10u * k1)) & 0x3ffu;        // phase + rank inside the segment (0 for plain bins: bits 30, 31)
-        const uint32_t two = (uint32_t)(k1 == 3u);
-        const uint32_t q = two ? x >> 1 : (x * 171u) >> 9;            // x / members per code, x < 256 + 3
-        const uint32_t mem = x - q * (3u - two);
-        const uint32_t opens = (uint32_t)(k1 != 0u) & (uint32_t)(mem == 0u);
-        nb[j] = (b[j] & 31u) + opens * ((d[j] >> 12) & 7u);
-        const uint32_t gbase = k1 == 1u ? (uint32_t)q3 : k1 == 2u ? (uint32_t)q5 : (uint32_t)q11;
-        R.gm[j] = (gbase + q) | (mem << 12);
-        run += inc[j];
-        nbsum += nb[j];
-        ndsum += zero[j] * (uint32_t)sb.mult;
-        // the opener publishes its code where the other members will look for it; everybody else writes to the sink
-        zero[j] = opens ? (k1 - 1u) * GC + (R.gm[j] & 0xfffu) : 3u * GC;      // (zero[] reused: gcode slot)
-    }
-    const uint32_t bl = nbsum | (ndsum << 16);
-    const uint32_t bin_ = wave_incl_scan_u32(bl);
-    const uint32_t off = sb.bit + (bin_ & 0xffffu) - nbsum;
-    R.cd = sb.draw + (int)(bin_ >> 16) - (int)ndsum;
-    // the lane's fields are at most 64 consecutive bits starting at `off`: a 64-bit window out of three dwords
-    uint32_t wi = off >> 5;
-    wi = wi < FB.last ? wi : FB.last;
-    const uint32_t d0 = frw[wi], d1 = frw[wi + 1], d2 = frw[wi + 2];
-    const uint32_t k = off & 31u;
-    uint64_t win = ((((uint64_t)d0 << 32) | d1) << k) | (uint64_t)((d2 >> 1) >> (31u - k));
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        R.raw[j] = ((uint32_t)(win >> 32) >> 1) >> (31u - nb[j]);       // top nb bits (0 for nb = 0)
-        win <<= nb[j];
-        L.gcode[zero[j]] = (uint8_t)R.raw[j];
-    }
+    (void)mant_first_half<GC, 0xfff, false>(L.exp + row_off(slot), L.bap + row_off(slot), L.desc, L.gcode, frw, FB.last, start, end,
+                                            slot == 5 ? LFE_ROW / 4 : 64, sb, R, lane);
 }
-
-// dequantised value of bin j before the exponent / gain scale (0 for a zero-bit bin)
-__device__ __forceinline__ float bin_q(const WgLDS &L, const BinRegs &R, int j)
-{
-    const uint32_t b = (R.bap4 >> (8 * j)) & 0xffu, k1 = b >> 5, nbp = b & 31u;
-    const uint32_t d = L.desc[b];
-    const uint32_t grp = R.gm[j] & 0xfffu, mem = R.gm[j] >> 12;
-    const uint32_t code = L.gcode[k1 ? (k1 - 1u) * GC + grp : 3u * GC];
-    const uint32_t coded = (d >> 15) & 1u;
-    const uint32_t qi = (d & 0x3ffu) + (k1 ? code * ((d >> 10) & 3u) + mem : R.raw[j]);
-    const float tv = L.qtab[coded ? qi : 0u];
-    const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
-    return coded ? tv : pv;
-}
+__device__ __forceinline__ float bin_q(const WgLDS &L, const BinRegs &R, int j) { return mant_value<GC, 0xfff>(R, j, L.desc, L.gcode, L.qtab); }
 
 // ---- the transformer: one block of all output planes per pass, 8 lanes per plane (xform_core.h arithmetic, as xform.hip).
 // Nothing stays in registers between its three parts: the transposed points and the first/tail values wait in the
@@ -856,16 +771,9 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
     // ---- constant tables ----
     for (int i = tid; i < 256; i += 512) { L.la_neg[i] = P.tab->la_neg[i]; L.band_of_bin[i] = P.tab->band_of_bin[i]; L.win[i] = W.window[i]; }
     if (tid < 64) {                                                  // row-byte form of the width table: see slot_census
-        const int w = P.tab->width[tid];
-        L.width[tid] = (int8_t)(w >= 0 ? w : -32 * w);
+        L.width[tid] = remap_width(P.tab->width[tid]);
     }
-    if (tid < 128) {
-        const uint32_t k1 = (uint32_t)tid >> 5, nbp = (uint32_t)tid & 31u;
-        const uint32_t qbase = k1 == 1 ? 0u : k1 == 2 ? 96u : k1 == 3 ? 480u : nbp == 3 ? 736u : nbp == 4 ? 744u : 0u;
-        const uint32_t per = k1 == 3 ? 2u : k1 ? 3u : 0u, obits = k1 == 1 ? 5u : k1 ? 7u : 0u;
-        const uint32_t coded = (k1 || nbp == 3 || nbp == 4) ? 1u : 0u;
-        L.desc[tid] = qbase | (per << 10) | (obits << 12) | (coded << 15);
-    }
+    if (tid < 128) L.desc[tid] = mant_desc((uint32_t)tid);
     if (tid < 30) L.band_end[tid] = P.tab->band_end[tid];
     if (tid < 50) L.hth[tid] = 0;
     for (int i = tid; i < 760; i += 512) L.qtab[i] = P.tab->qtab[i];
@@ -982,13 +890,13 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                             const bool in = wave != 5 || i < LFE_ROW;
                             const int bb = in ? L.bap[row_off(wave) + i] : 0;
                             te[wave * 256 + i] = in ? L.exp[row_off(wave) + i] : 0;
-                            tb[wave * 256 + i] = (int8_t)(bb >= 32 ? -(bb >> 5) : bb);          // liba52's form: -1 / -2 / -3 for grouped codes
+                            tb[wave * 256 + i] = unmap_width(bb);          // liba52's form: -1 / -2 / -3 for grouped codes
                         }
                         if (wave == W_LFE)
                             for (int i = lane; i < 256; i += 64) {
                                 const int bb = L.bap[row_off(6) + i];
                                 te[6 * 256 + i] = L.exp[row_off(6) + i];
-                                tb[6 * 256 + i] = (int8_t)(bb >= 32 ? -(bb >> 5) : bb);
+                                tb[6 * 256 + i] = unmap_width(bb);
                             }
                     }
                 } else if (wave == W_XFORM && blk > 0) {
