@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 #pragma unroll
             for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
             any = false;
-#pragma unroll
+#pragma unroll 1
             for (int k = 0; k < 6; k++) {
                 if (k >= pcnt) continue;
                 const int c = (plist >> (3 * k)) & 7;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 #pragma unroll
                 for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
                 any = false;
-#pragma unroll
+#pragma unroll 1
                 for (int k = 0; k < 6; k++) {
                     if (k >= pcnt) continue;
                     const int c = (plist >> (3 * k)) & 7;
@@ -336,8 +336,8 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     }
     if (identity)
         hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, P);
-    else        // 187 VGPRs: 2 workgroups per CU; forced to 3 it spills and runs 1.26 ms instead of 0.81 (65 536 frames, 5.1 -> 2.0)
-        hipLaunchKernelGGL((xform_kernel<true, 2>), dim3(grid), dim3(256), 0, stream, P);
+    else        // 167 VGPRs with the planes of an output accumulated one after the other (187 with their loads unrolled): 3 workgroups per CU
+        hipLaunchKernelGGL((xform_kernel<true, 3>), dim3(grid), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

@@ -96,6 +96,83 @@ __global__ __launch_bounds__(256) void copy_rows_wave(const float4 *__restrict__
     }
 }
 
+// variants of the transform's addressing -------------------------------------------------------------------------
+// (a) 16 bytes per lane: lane l8 moves float4 number l8 + 8 n (n < 8) of its plane: 128 contiguous bytes per group
+__global__ __launch_bounds__(256) void copy_rows_group8_f4(const float4 *__restrict__ a, float4 *__restrict__ b, int n_chains, int blocks, int cps)
+{
+    extern __shared__ float pad_[];
+    const int group = blockIdx.x * 32 + (threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    if (group >= n_chains) return;
+    const int s = group / cps, o = group - s * cps;
+    const size_t base = ((size_t)s * blocks * cps + o) * 64;
+    for (int blk = 0; blk < blocks; blk++) {
+        const float4 *p = a + base + (size_t)blk * cps * 64 + l8;
+        float4 *q = b + base + (size_t)blk * cps * 64 + l8;
+        float4 v[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) v[n] = p[8 * n];
+#pragma unroll
+        for (int n = 0; n < 8; n++) q[8 * n] = v[n];
+    }
+}
+// (b) as the 8-byte baseline, but the next block's loads are issued before this block's stores
+__global__ __launch_bounds__(256) void copy_rows_group8_pf(const float2 *__restrict__ a, float2 *__restrict__ b, int n_chains, int blocks, int cps)
+{
+    extern __shared__ float pad_[];
+    const int group = blockIdx.x * 32 + (threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    if (group >= n_chains) return;
+    const int s = group / cps, o = group - s * cps;
+    const size_t base = ((size_t)s * blocks * cps + o) * 128;
+    float2 v[16], w[16];
+#pragma unroll
+    for (int n = 0; n < 16; n++) v[n] = a[base + l8 + 8 * n];
+    for (int blk = 0; blk < blocks; blk++) {
+        const int nb = blk + 1 < blocks ? blk + 1 : blk;
+#pragma unroll
+        for (int n = 0; n < 16; n++) w[n] = a[base + (size_t)nb * cps * 128 + l8 + 8 * n];
+        float2 *q = b + base + (size_t)blk * cps * 128 + l8;
+#pragma unroll
+        for (int n = 0; n < 16; n++) q[8 * n] = v[n];
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = w[n];
+    }
+}
+// (c) the baseline with dynamic LDS padding (occupancy cap) - same kernel body as copy_rows_group8
+__global__ __launch_bounds__(256) void copy_rows_group8_pad(const float2 *__restrict__ a, float2 *__restrict__ b, int n_chains, int blocks, int cps)
+{
+    extern __shared__ float pad_[];
+    const int group = blockIdx.x * 32 + (threadIdx.x >> 3), l8 = threadIdx.x & 7;
+    if (group >= n_chains) return;
+    const int s = group / cps, o = group - s * cps;
+    const size_t base = ((size_t)s * blocks * cps + o) * 128;
+    for (int blk = 0; blk < blocks; blk++) {
+        const float2 *p = a + base + (size_t)blk * cps * 128 + l8;
+        float2 *q = b + base + (size_t)blk * cps * 128 + l8;
+        float2 v[16];
+#pragma unroll
+        for (int n = 0; n < 16; n++) v[n] = p[8 * n];
+#pragma unroll
+        for (int n = 0; n < 16; n++) q[8 * n] = v[n];
+    }
+}
+// (d) a workgroup streams whole stream-blocks: 256 threads x 16 bytes = 4 KB contiguous per instruction, 6 KB per block of a
+//     stream, streams of a workgroup back to back (what a transform that redistributes through LDS would read and write)
+__global__ __launch_bounds__(256) void copy_streams_flat(const float4 *__restrict__ a, float4 *__restrict__ b, int n_streams, int streams_per_wg, int f4_per_stream)
+{
+    extern __shared__ float pad_[];
+    const int s0 = blockIdx.x * streams_per_wg;
+    const int ns = s0 + streams_per_wg <= n_streams ? streams_per_wg : n_streams - s0;
+    if (ns <= 0) return;
+    const size_t base = (size_t)s0 * f4_per_stream, n = (size_t)ns * f4_per_stream;
+    for (size_t i = threadIdx.x; i < n; i += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + 256 * k < n ? a[base + i + 256 * k] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i + 256 * k < n) b[base + i + 256 * k] = v[k];
+    }
+}
+
 // ---- issue probes: 8 wavefronts per SIMD, nothing but register arithmetic --------------------------------------
 __global__ __launch_bounds__(256) void salu_probe(uint32_t *out, int iters)
 {
@@ -214,6 +291,34 @@ int main()
         printf("copy 1 KiB rows, 8-lane group per chain (the transform's addressing) 2.42 GB/array : %.3f ms  %.0f GB/s\n", ms, 2.0 * bytes / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(copy_rows_wave, dim3(((int)frames + 3) / 4), dim3(256), 0, 0, a, b, (int)frames, 6, 6); });
         printf("copy 1 KiB rows, wavefront per stream, 16 B per lane                  2.42 GB/array : %.3f ms  %.0f GB/s\n", ms, 2.0 * bytes / ms / 1e6);
+    }
+    {
+        const int chains = (int)frames * 6;
+        const int grid = (chains + 31) / 32;
+        printf("# variants of the transform's addressing (2.42 GB per array, 32 chains per workgroup)\n");
+        for (int lds : {0, 40960, 53248, 81920}) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(copy_rows_group8_pad, dim3(grid), dim3(256), lds, 0, (const float2 *)a, (float2 *)b, chains, 6, 6); });
+            printf("8 B/lane baseline, %5d B LDS per workgroup (occupancy cap): %.3f ms  %.0f GB/s\n", lds, ms, 2.0 * bytes / ms / 1e6);
+        }
+        for (int lds : {0, 53248}) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(copy_rows_group8_f4, dim3(grid), dim3(256), lds, 0, a, b, chains, 6, 6); });
+            printf("16 B/lane (128 B per group), %5d B LDS: %.3f ms  %.0f GB/s\n", lds, ms, 2.0 * bytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL(copy_rows_group8_pf, dim3(grid), dim3(256), lds, 0, (const float2 *)a, (float2 *)b, chains, 6, 6); });
+            printf("8 B/lane, next block's loads before this block's stores, %5d B LDS: %.3f ms  %.0f GB/s\n", lds, ms, 2.0 * bytes / ms / 1e6);
+        }
+        // how much a workgroup may stream before the rate drops: contiguous chunks of 4 .. 36 KB per workgroup
+        for (int kb : {4, 8, 12, 24, 36}) {
+            const int f4 = kb * 64, g2 = (int)(bytes / 16 / f4);
+            double ms = time_ms([&] { hipLaunchKernelGGL(copy_streams_flat, dim3(g2), dim3(256), 0, 0, a, b, g2, 1, f4); });
+            printf("contiguous %2d KB per workgroup, then the workgroup ends: %.3f ms  %.0f GB/s\n", kb, ms, 2.0 * (double)g2 * f4 * 16 / ms / 1e6);
+        }
+        for (int spw : {1, 2, 4, 8}) {
+            for (int lds : {0, 40960}) {
+                const int g2 = ((int)frames + spw - 1) / spw;
+                double ms = time_ms([&] { hipLaunchKernelGGL(copy_streams_flat, dim3(g2), dim3(256), lds, 0, a, b, (int)frames, spw, 36 * 64); });
+                printf("whole streams (36 KB contiguous each), %d per workgroup, %5d B LDS: %.3f ms  %.0f GB/s\n", spw, lds, ms, 2.0 * bytes / ms / 1e6);
+            }
+        }
     }
     printf("# issue probes: 8 wavefronts per SIMD, 10^9 instructions per second and SIMD\n");
     {
