@@ -25,7 +25,8 @@ class DecodeDescC(ctypes.Structure):
 
 
 class DecodeTapsC(ctypes.Structure):
-    _fields_ = [("d_coef", c_void_p), ("d_blksw", c_void_p), ("d_exp", c_void_p), ("d_bap", c_void_p)]
+    _fields_ = [("d_coef", c_void_p), ("d_blksw", c_void_p), ("d_exp", c_void_p), ("d_bap", c_void_p),
+                ("d_dynrng_out", c_void_p), ("d_dynrng_in", c_void_p)]
 
 
 class EncodeDescC(ctypes.Structure):
@@ -106,6 +107,7 @@ def load_library():
                                        c_void_p, c_int, c_int, c_int, ctypes.POINTER(EncodeTapsC)]
     lib.ac3mi_set_decode_mode.argtypes = [c_void_p, ctypes.c_int]
     lib.ac3mi_probe_valu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
+    lib.ac3mi_probe_salu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_set_tile_frames.argtypes = [c_void_p, ctypes.c_longlong]
     lib.ac3mi_transcode_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), ctypes.POINTER(EncodeDescC), c_void_p, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

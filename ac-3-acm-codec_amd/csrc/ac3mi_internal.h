@@ -92,6 +92,8 @@ struct DecodeLaunch {
     uint16_t *lfsr;         // [S]
     uint8_t *tap_exp;
     int8_t *tap_bap;
+    float *dyn_out = nullptr;           // [S][F][6][2] range factors of the stream's dynamic-range words (NaN: none)
+    const float *dyn_in = nullptr;      // [S][F][6][2] replacements (NaN: keep)
     const int32_t *slot;
     // few long streams: counting pass + LFSR prefix + one wavefront per frame (decode.hip, MODE 1/2)
     int frame_parallel;

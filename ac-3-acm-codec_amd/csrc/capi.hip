@@ -354,6 +354,24 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(uint32_t *out, int iter
     const uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
     if (r == 0x12345678u) out[0] = r;               // keeps the chain alive; practically never taken
 }
+// the same for the scalar unit: iters x 32 s_add_u32 / s_xor_b32 on four independent registers per wavefront
+__global__ __launch_bounds__(256) void salu_probe_kernel(uint32_t *out, int iters)
+{
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    for (int i = 0; i < iters; i++) {
+        asm volatile(
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            "s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 3\n s_add_u32 %2, %2, 5\n s_xor_b32 %3, %3, 7\n"
+            : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+    }
+    if ((s0 ^ s1 ^ s2 ^ s3) == 0x12345678u) out[0] = s0;
+}
 }  // namespace ac3mi
 
 extern "C" {
@@ -558,6 +576,27 @@ int ac3mi_probe_valu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd)
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     (void)hipFree(d);
     // per SIMD: wg_per_cu workgroups x 4 wavefronts / 4 SIMDs = wg_per_cu wavefronts, 32 instructions per iteration each
+    *ginst_per_s_per_simd = (double)wg_per_cu * iters * 32.0 / (ms * 1e-3) / 1e9;
+    return AC3MI_OK;
+}
+
+int ac3mi_probe_salu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd)
+{
+    if (!ctx || !ginst_per_s_per_simd) return AC3MI_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount, wg_per_cu = 8, iters = 4096;        // 8 wavefronts per SIMD
+    uint32_t *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, 64));
+    hipLaunchKernelGGL(salu_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, 64);       // warm-up
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(salu_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, iters);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    (void)hipFree(d);
     *ginst_per_s_per_simd = (double)wg_per_cu * iters * 32.0 / (ms * 1e-3) / 1e9;
     return AC3MI_OK;
 }
@@ -802,6 +841,8 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.slot = ctx->slots;
         D.tap_exp = taps && taps->d_exp ? taps->d_exp : nullptr;
         D.tap_bap = taps && taps->d_bap ? taps->d_bap : nullptr;
+        D.dyn_out = taps ? taps->d_dynrng_out : nullptr;
+        D.dyn_in = taps ? taps->d_dynrng_in : nullptr;
         D.frame_parallel = 0;
         D.frame_draws = nullptr;
         D.frame_lfsr = nullptr;
@@ -851,6 +892,8 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
         D.tap_exp = taps && taps->d_exp ? taps->d_exp + f0 * 6 * 7 * 256 : nullptr;
         D.tap_bap = taps && taps->d_bap ? taps->d_bap + f0 * 6 * 7 * 256 : nullptr;
+        D.dyn_out = taps && taps->d_dynrng_out ? taps->d_dynrng_out + f0 * 12 : nullptr;
+        D.dyn_in = taps && taps->d_dynrng_in ? taps->d_dynrng_in + f0 * 12 : nullptr;
         D.frame_parallel = fp ? 1 : 0;
         D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
         D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;

@@ -178,15 +178,13 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
                 // ---- side information: parse.c:572-701 ----
                 for (int i = 0; i < nf; i++) blkswm |= rd.get(1) << i;
                 for (int i = 0; i < nf; i++) dithmask |= rd.get(1) << i;
-                int twice = !st.acmod;
+                int twice = !st.acmod, word = 0;
                 do {
                     if (rd.get(1)) {
                         const int code = rd.sget(8);
-                        if (st.dynrnge) {
-                            const float range = (float)(((code & 0x1f) | 0x20) << 13) * sf_of(3 - (code >> 5));
-                            st.dynrng = st.level * range;
-                        }
+                        if (st.dynrnge) st.dynrng = st.level * dynrng_range(P, code, (fidx * 6 + blk) * 2 + word, lane);
                     }
+                    word++;
                 } while (twice--);
 
                 if (rd.get(1)) {                                            // cplstre
@@ -612,6 +610,8 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
     P.frame_draws = L.frame_draws;
     P.frame_lfsr = L.frame_lfsr;
+    P.dyn_out = L.dyn_out;
+    P.dyn_in = L.dyn_in;
     static const int lds_pad = getenv("AC3MI_DEC_LDS_PAD") ? atoi(getenv("AC3MI_DEC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
     const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + lds_pad;
     if (!L.frame_parallel) {
@@ -622,6 +622,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     DecodeParams C = P;                                 // counting pass: no outputs but the draw counts
     C.tap_exp = nullptr;
     C.tap_bap = nullptr;
+    C.dyn_out = nullptr;
     hipLaunchKernelGGL(decode_kernel<1>, dim3(units), dim3(64), fr_bytes, stream, C);
     hipLaunchKernelGGL(lfsr_prefix_kernel, dim3((L.n_streams + 63) / 64), dim3(64), 0, stream, (const uint32_t *)L.frame_draws,
                        L.frame_lfsr, (const uint16_t *)L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);

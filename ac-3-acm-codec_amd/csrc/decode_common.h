@@ -139,7 +139,21 @@ struct DecodeParams {
     const int32_t *slot;    // optional: stream s keeps its LFSR state in lfsr_state[slot[s]]
     uint32_t *frame_draws;  // [S][F] dither draws of each frame (written by the counting pass)
     const uint16_t *frame_lfsr;   // [S][F] LFSR state at the start of each frame (frame-parallel pass)
+    float *dyn_out;               // optional [S][F][6][2], see ac3mi_decode_taps
+    const float *dyn_in;
 };
+
+// the range factor of a dynamic-range word (parse.c:587-595), through the optional per-word taps
+__device__ __forceinline__ float dynrng_range(const DecodeParams &P, int code, size_t word_index, int lane)
+{
+    float range = (float)(((code & 0x1f) | 0x20) << 13) * __int_as_float((127 - 15 - (3 - (code >> 5))) << 23);
+    if (P.dyn_out && lane == 0) P.dyn_out[word_index] = range;
+    if (P.dyn_in) {
+        const float r = P.dyn_in[word_index];
+        if (r == r) range = r;                           // NaN = keep the stream's own
+    }
+    return range;
+}
 
 // ---------------------------------------------------------------------------
 // exponents: L52/parse.c:218-270.  ngrps groups of 7 bits at `pos`; returns 1 on a

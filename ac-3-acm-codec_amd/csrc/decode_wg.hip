@@ -207,7 +207,8 @@ struct ParserState {
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
-__device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, const BlkInfo &prev, int blk, int lane, unsigned long long *dbg = nullptr)
+__device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, const BlkInfo &prev, int blk, int lane, const DecodeParams &P, size_t fidx,
+                              unsigned long long *dbg = nullptr)
 {
     PSTAMP(0);
     VRd rd = make_reader(FB, (uint32_t)ldsu((const int &)S.pos), lane);
@@ -220,15 +221,13 @@ __device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, co
     do {
         for (int i = 0; i < nf; i++) blkswm |= rd.get(1) << i;
         for (int i = 0; i < nf; i++) dithmask |= rd.get(1) << i;
-        int twice = !acmod;
+        int twice = !acmod, word = 0;
         do {
             if (rd.get(1)) {
                 const int code = rd.sget(8);
-                if (ldsu(S.dynrnge)) {
-                    const float range = (float)(((code & 0x1f) | 0x20) << 13) * sf_of(3 - (code >> 5));
-                    PSET(S.dynrng, ldsf(S.level) * range);
-                }
+                if (ldsu(S.dynrnge)) PSET(S.dynrng, ldsf(S.level) * dynrng_range(P, code, (fidx * 6 + blk) * 2 + word, lane));
             }
+            word++;
         } while (twice--);
 
         PSTAMP(2);
@@ -838,7 +837,7 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                 if (!ok) PSET(S.status, 0x100u);
                 BlkInfo &B0 = L.bi[0];
                 if (ok) {
-                    parse_block_a(FB, S, B0, L.bi[1], 0, lane);
+                    parse_block_a(FB, S, B0, L.bi[1], 0, lane, P, fidx);
                     wave_sync();
                     parse_block_b(FB, S, B0, L.deltba, 0, lane);
                 } else PSET(B0.err, 1);
@@ -951,9 +950,9 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                     }
                     if (blk < 5) {
 #ifdef WG_STAMPS
-                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane, (W.stamps && blockIdx.x == 0 && s == (int)gridDim.x && f == 0 && blk == 2) ? W.stamps + wave * 64 + 56 : nullptr);
+                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane, P, fidx, (W.stamps && blockIdx.x == 0 && s == (int)gridDim.x && f == 0 && blk == 2) ? W.stamps + wave * 64 + 56 : nullptr);
 #else
-                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane);
+                        if (!dead) parse_block_a(FB, S, Bn, B, blk + 1, lane, P, fidx);
 #endif
                         else PSET(Bn.err, 1);
                     }
@@ -1144,6 +1143,8 @@ hipError_t launch_decode_wg(const DeviceTables &tab, const DecodeLaunch &D, cons
     P.n_in = P.nfchans + (D.lfeon ? 1 : 0);
     P.frame_draws = nullptr;
     P.frame_lfsr = nullptr;
+    P.dyn_out = D.dyn_out;
+    P.dyn_in = D.dyn_in;
     W.tw_long = tab.tw_long;
     W.tw_short = tab.tw_short;
     W.window = tab.window;

@@ -105,11 +105,15 @@ struct a52_state_s {
     float level_in, bias;
     uint32_t status;
     float pcm[6 * 6 * 256];
+    level_t (*dyn_call)(level_t, void *);     // a52_dynrng callback of the current frame (parse.c:207-216)
+    void *dyn_data;
     // device side
     uint8_t *d_frame;
     float *d_delay, *d_pcm;
     uint16_t *d_lfsr;
     uint32_t *d_status;
+    float *d_dyn;               // 12 range factors out + 12 in (callback frames only)
+    float *d_scratch;           // overlap tails + dither state of the look-ahead pass
 };
 
 extern "C" {
@@ -142,7 +146,9 @@ a52_state_t *a52_init(uint32_t mm_accel)
     st->d_pcm = (float *)ac3mi_dev_alloc(ctx, sizeof st->pcm);
     st->d_lfsr = (uint16_t *)ac3mi_dev_alloc(ctx, 4);
     st->d_status = (uint32_t *)ac3mi_dev_alloc(ctx, 4);
-    if (!st->samples || !st->d_frame || !st->d_delay || !st->d_pcm || !st->d_lfsr || !st->d_status) {
+    st->d_dyn = (float *)ac3mi_dev_alloc(ctx, 24 * sizeof(float));
+    st->d_scratch = (float *)ac3mi_dev_alloc(ctx, 6 * 128 * sizeof(float) + 16);
+    if (!st->samples || !st->d_frame || !st->d_delay || !st->d_pcm || !st->d_lfsr || !st->d_status || !st->d_dyn || !st->d_scratch) {
         a52_free(st);
         return nullptr;
     }
@@ -186,7 +192,9 @@ int a52_frame(a52_state_t *st, uint8_t *buf, int *flags, level_t *level, sample_
     *flags = out;
     st->out_flags = out;
     st->bias = bias;
-    st->dynrng = 1;                                      // state->dynrnge = 1 (parse.c:171)
+    st->dynrng = 1;                                      // state->dynrnge = 1, state->dynrngcall = NULL (parse.c:171-172)
+    st->dyn_call = nullptr;
+    st->dyn_data = nullptr;
     if (n <= 0 || n > 3840) {                            // liba52 would parse garbage; we report block errors
         st->frame_bytes = 0;
         st->have_frame = 1;
@@ -205,8 +213,9 @@ int a52_frame(a52_state_t *st, uint8_t *buf, int *flags, level_t *level, sample_
 
 void a52_dynrng(a52_state_t *st, level_t (*call)(level_t, void *), void *data)
 {
-    (void)data;
-    st->dynrng = call ? 1 : 0;                           // a callback cannot run on the GPU: see header
+    st->dynrng = call ? 1 : 0;                           // parse.c:207-216
+    st->dyn_call = call;
+    st->dyn_data = data;
 }
 
 static int dropin_decode(a52_state_t *st)
@@ -226,8 +235,30 @@ static int dropin_decode(a52_state_t *st)
     st->n_out = n_out;
     const int stride = (st->frame_bytes + 3) & ~3;
     if (ac3mi_memcpy_h2d(ctx, st->d_frame, st->frame, stride) != AC3MI_OK) return -1;
+    ac3mi_decode_taps taps;
+    memset(&taps, 0, sizeof taps);
+    if (st->dyn_call) {
+        // The callback is host code: a look-ahead pass on scratch copies of the carry-over state reports the range factor of
+        // every dynamic-range word of the frame, the callback maps them in stream order (liba52 calls it from inside
+        // a52_block, parse.c:593-594; here all calls of a frame happen at its first a52_block), and the frame is decoded
+        // with the mapped values in their place.
+        float words[12], mapped[12];
+        uint16_t *d_lfsr2 = (uint16_t *)(st->d_scratch + 6 * 128);
+        if (hipMemcpyAsync(st->d_scratch, st->d_delay, 6 * 128 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_lfsr2, st->d_lfsr, 2, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            return -1;
+        for (int i = 0; i < 12; i++) words[i] = __builtin_nanf("");
+        if (ac3mi_memcpy_h2d(ctx, st->d_dyn, words, sizeof words) != AC3MI_OK) return -1;
+        taps.d_dynrng_out = st->d_dyn;
+        if (ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_scratch, d_lfsr2, st->d_pcm, st->d_status, &taps) != AC3MI_OK) return -1;
+        if (ac3mi_memcpy_d2h(ctx, words, st->d_dyn, sizeof words) != AC3MI_OK) return -1;
+        for (int i = 0; i < 12; i++) mapped[i] = words[i] == words[i] ? st->dyn_call(words[i], st->dyn_data) : words[i];
+        if (ac3mi_memcpy_h2d(ctx, st->d_dyn + 12, mapped, sizeof mapped) != AC3MI_OK) return -1;
+        taps.d_dynrng_out = nullptr;
+        taps.d_dynrng_in = st->d_dyn + 12;
+    }
     if (ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_delay, st->d_lfsr, st->d_pcm, st->d_status,
-                           nullptr) != AC3MI_OK)
+                           st->dyn_call ? &taps : nullptr) != AC3MI_OK)
         return -1;
     if (ac3mi_memcpy_d2h(ctx, st->pcm, st->d_pcm, (size_t)6 * n_out * 256 * sizeof(float)) != AC3MI_OK) return -1;
     if (ac3mi_memcpy_d2h(ctx, &st->status, st->d_status, 4) != AC3MI_OK) return -1;
@@ -257,6 +288,8 @@ void a52_free(a52_state_t *st)
         ac3mi_dev_free(ctx, st->d_pcm);
         ac3mi_dev_free(ctx, st->d_lfsr);
         ac3mi_dev_free(ctx, st->d_status);
+        ac3mi_dev_free(ctx, st->d_dyn);
+        ac3mi_dev_free(ctx, st->d_scratch);
     }
     free(st->samples);
     free(st);

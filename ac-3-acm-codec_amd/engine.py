@@ -147,7 +147,7 @@ class Engine:
             raise capi.AC3MIError("a52_frame would refuse flags %d for acmod %d" % (desc.flags, desc.acmod))
         return n_out.value, fl.value
 
-    def decode_batch(self, desc, frames, delay, lfsr, out=None, status=None, taps=False, wait_torch=True):
+    def decode_batch(self, desc, frames, delay, lfsr, out=None, status=None, taps=False, wait_torch=True, dynrng_in=None):
         """frames [S][F][stride] u8 (stride multiple of 4), delay [S][n_out][128] f32, lfsr [S] i16/u16
         (both updated in place) -> (pcm [S][F][6][n_out][256] f32, status [S][F] i32[, taps dict])."""
         import torch
@@ -171,8 +171,10 @@ class Engine:
                 "exp": torch.zeros((S, F, 6, 7, 256), dtype=torch.uint8, device=dev),
                 "bap": torch.zeros((S, F, 6, 7, 256), dtype=torch.int8, device=dev),
             }
+            tdict["dynrng"] = torch.full((S, F, 6, 2), float("nan"), dtype=torch.float32, device=dev)
             tp = capi.DecodeTapsC(tdict["coef"].data_ptr(), tdict["blksw"].data_ptr(), tdict["exp"].data_ptr(),
-                                  tdict["bap"].data_ptr())
+                                  tdict["bap"].data_ptr(), tdict["dynrng"].data_ptr(),
+                                  dynrng_in.data_ptr() if dynrng_in is not None else None)
         c = desc.c()
         self._drain_torch(wait_torch or taps)
         self._check(self.lib.ac3mi_decode_batch(self.ctx, ctypes.byref(c), frames.data_ptr(), stride, S, F,
@@ -208,6 +210,12 @@ class Engine:
         """10^9 VALU instructions/s one SIMD sustains under a chip-wide VALU load (ac3mi_probe_valu_rate)."""
         v = ctypes.c_double()
         self._check(self.lib.ac3mi_probe_valu_rate(ctypes.c_void_p(self.ctx), ctypes.byref(v)))
+        return v.value
+
+    def probe_salu_rate(self):
+        """10^9 scalar instructions/s one SIMD's share of the scalar unit sustains under a chip-wide load (ac3mi_probe_salu_rate)."""
+        v = ctypes.c_double()
+        self._check(self.lib.ac3mi_probe_salu_rate(ctypes.c_void_p(self.ctx), ctypes.byref(v)))
         return v.value
 
     def set_tile_frames(self, frames):

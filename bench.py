@@ -180,7 +180,7 @@ def instruction_mix():
 N_SIMD = 256 * 4           # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def leg_rooflines(name, nbytes, fps, probe_ginst, mix):
+def leg_rooflines(name, nbytes, fps, probe_ginst, mix, probe_salu=None):
     """The two ceilings of a secondary leg.  hbm: algorithmic bytes x frames/s against 8 TB/s.
     valu_issue: VALU instructions per frame (committed PMC summary, named in `source`) x frames/s against what all SIMDs
     issue, measured by ac3mi_probe_valu_rate in this very run."""
@@ -195,6 +195,14 @@ def leg_rooflines(name, nbytes, fps, probe_ginst, mix):
                              "frac": valu * fps / 1e9 / peak, "valu_per_frame": valu, "salu_per_frame": salu,
                              "kernels": leg, "source": mix.get("file"),
                              "peak_source": "ac3mi_probe_valu_rate of this run x %d SIMDs" % N_SIMD}
+        if probe_salu:
+            speak = probe_salu * N_SIMD
+            out["salu_issue"] = {"bound": "salu_issue", "achieved": salu * fps / 1e9, "peak": speak, "unit": "Ginst/s",
+                                 "frac": salu * fps / 1e9 / speak, "salu_per_frame": salu, "source": mix.get("file"),
+                                 "peak_source": "ac3mi_probe_salu_rate of this run x %d SIMDs" % N_SIMD}
+            # one wavefront issues its vector and scalar instructions in order: the two shares add up
+            out["issue"] = {"bound": "valu+salu issue", "frac": out["valu_issue"]["frac"] + out["salu_issue"]["frac"],
+                            "note": "sum of the two fractions: share of the issue slots the leg's instruction counts need at its measured rate"}
     else:
         out["valu_issue"] = None
     return out
@@ -325,12 +333,15 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5, checks=Tru
                      "algorithmic_bytes_per_frame": nbytes}
     # the issue ceiling of the instruction-bound kernels: plain VALU instructions per second and SIMD, chip-wide load
     rate = eng.probe_valu_rate()
+    srate = eng.probe_salu_rate()
+    res["salu_probe"] = {"ginst_per_s_per_simd": srate,
+                         "note": "scalar instructions per second and SIMD (one scalar unit per CU, shared by its four SIMDs), chip-wide load"}
     res["valu_probe"] = {"ginst_per_s_per_simd": rate,
                          "note": "plain 32-bit VALU instructions one SIMD sustains with all SIMDs busy (8 wavefronts each); "
                                  "the valu_issue rooflines of the legs are priced against this x %d SIMDs" % N_SIMD}
     mix = instruction_mix()
     for name in ("encode", "decode", "decode_s16", "transcode", "transform_downmix_mixed_blocks"):
-        res[name]["roofline"] = leg_rooflines(name, res[name]["algorithmic_bytes_per_frame"], res[name]["frames_per_s_per_gpu"], rate, mix)
+        res[name]["roofline"] = leg_rooflines(name, res[name]["algorithmic_bytes_per_frame"], res[name]["frames_per_s_per_gpu"], rate, mix, srate)
     # ---- untimed epilogue: every leg's verdict on the whole batch, from its own buffers ----
     eng.sync()
     torch.cuda.synchronize(dev)

@@ -77,6 +77,9 @@ int ac3mi_timer_stop(ac3mi_ctx *ctx, float *elapsed_ms);   /* synchronises */
  * doing the same (a gfx950 SIMD issues a wave64 VALU instruction in 2 cycles).  DESIGN.md prices the decode / encode
  * kernels against it. */
 int ac3mi_probe_valu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd);
+/* the same for scalar (SALU) instructions: the scalar unit issues about half as fast as a SIMD's vector pipe, so for the
+ * front ends and the packer - a third or more of whose instructions are scalar - it is the tighter of the two ceilings */
+int ac3mi_probe_salu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd);
 
 /* ---- block transform: IMDCT-512/256 + KBD window + overlap-add + downmix ---- */
 
@@ -184,6 +187,11 @@ typedef struct {
     uint8_t *d_blksw;   /* [S][F][6][nfchans] */
     uint8_t *d_exp;     /* [S][F][6][7][256] exponents after each block: 0-4 fbw, 5 lfe, 6 coupling */
     int8_t *d_bap;      /* [S][F][6][7][256] bits per mantissa (liba52 convention, L52/bit_allocate.c:49-72) */
+    /* dynamic-range words, for hosts that registered an a52_dynrng() callback (L52/parse.c:207-216, 580-597): [S][F][6][2]
+     * floats, word 1 only in dual-mono streams.  d_dynrng_out receives the range factor of every word the stream carries
+     * (NaN where there is none) as liba52 would hand it to the callback; d_dynrng_in replaces them (NaN = keep). */
+    float *d_dynrng_out;
+    const float *d_dynrng_in;
 } ac3mi_decode_taps;
 
 /* a52_syncinfo (L52/parse.c:86-129), host side: frame size in bytes, 0 if not a frame */

@@ -13,9 +13,10 @@
  *   - a52_init() returns NULL when no GPU is visible (there is no CPU fallback)
  *   - the work of a52_frame() is deferred to the first a52_block(): all six blocks are decoded by one
  *     launch, a52_block() then hands them out; return codes are the same
- *   - a52_dynrng() with a callback: the callback cannot run on the GPU; it is ignored and the stream's
- *     own dynamic-range words apply (as if no callback were given).  a52_dynrng(state, NULL, NULL)
- *     works as in liba52
+ *   - a52_dynrng() with a callback: the callback is host code, so the frame is decoded twice - a look-ahead pass
+ *     reports the range factor of every dynamic-range word, the callback maps them in stream order, the second
+ *     pass uses the mapped values (same samples as liba52).  All calls of a frame happen at its first a52_block()
+ *     rather than one inside each a52_block().  a52_dynrng(state, NULL, NULL) works as in liba52
  *   - after a52_block() has returned 1 for a block, the remaining blocks of that frame also return 1
  *     (liba52 would continue parsing from a corrupted position)
  */

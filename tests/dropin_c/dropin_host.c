@@ -5,7 +5,7 @@
  * (a52dec-0.7.5-cvs/src/a52dec.c:270-305) and of stream_convert_pcm (src/AC3ACM.cpp:1762),
  * with files instead of ACM buffers.
  *
- *   dropin_host dec <in.ac3> <out.f32> <out.s16> <flags> <level> <bias> <dynrng_off>
+ *   dropin_host dec <in.ac3> <out.f32> <out.s16> <flags> <level> <bias> <dynrng: 0 stream's own, 1 off, 2 callback>
  *   dropin_host enc <in.s16> <out.ac3> <freq> <bitrate> <channels>
  */
 #include <stdint.h>
@@ -23,8 +23,17 @@ static int nchans(int flags)
     return n[flags & A52_CHANNEL_MASK] + ((flags & A52_LFE) ? 1 : 0);
 }
 
+/* a dynamic-range callback as a52dec's -c / compression hooks are written (a52dec.c:291): exact in float */
+static int callback_calls;
+static level_t halve_range(level_t range, void *data)
+{
+    callback_calls++;
+    return range * *(float *)data;
+}
+
 static int decode(int argc, char **argv)
 {
+    static float half = 0.5f;
     FILE *in = fopen(argv[2], "rb"), *of = fopen(argv[3], "wb"), *os = fopen(argv[4], "wb");
     int req = atoi(argv[5]), dynoff = atoi(argv[8]);
     float level0 = (float)atof(argv[6]), bias = (float)atof(argv[7]);
@@ -41,7 +50,8 @@ static int decode(int argc, char **argv)
         if (fread(buf + 8, 1, len - 8, in) != (size_t)(len - 8)) break;
         flags = req;
         if (a52_frame(st, buf, &flags, &level, bias)) { errors++; continue; }
-        if (dynoff) a52_dynrng(st, NULL, NULL);
+        if (dynoff == 1) a52_dynrng(st, NULL, NULL);
+        if (dynoff == 2) a52_dynrng(st, halve_range, &half);
         for (b = 0; b < 6; b++) {
             int n = nchans(flags);
             if (a52_block(st)) { errors++; break; }
@@ -56,7 +66,7 @@ static int decode(int argc, char **argv)
     }
     a52_free(st);
     fclose(in); fclose(of); fclose(os);
-    printf("frames %d errors %d\n", frames, errors);
+    printf("frames %d errors %d callback calls %d\n", frames, errors, callback_calls);
     return errors ? 1 : 0;
 }
 

@@ -112,3 +112,49 @@ def test_secondary_liba52_exports_imdct(engine):
         if R is not None:
             (R.a52_imdct_256 if k else R.a52_imdct_512)(H.P(r, H.fp), H.P(d_ref, H.fp), bias)
             assert H.rms(g.astype(np.float64) - r) <= (1e-6 if bias != 384.0 else 4e-5)
+
+
+def test_c_host_dynrng_callback(host_exe, tmp_path):
+    """a52_dynrng with a callback (liba52/parse.c:207-216, 593-594) on packer streams that carry dynamic-range words: the
+    C host registers a function that halves every range factor; same samples as the oracle with the same callback."""
+    import ctypes
+    from tests import packer
+    L = H.orc()
+    for acmod, lfe, flags in ((7, 1, 7 | 16), (2, 0, 2), (0, 0, 0)):
+        frames = packer.make_stream(9100 + acmod, 4, acmod, lfe)
+        fb = frames.shape[1]
+        (tmp_path / "in.ac3").write_bytes(frames.tobytes())
+        r = subprocess.run([host_exe, "dec", str(tmp_path / "in.ac3"), str(tmp_path / "o.f32"), str(tmp_path / "o.s16"),
+                            str(flags), "1.0", "0.0", "2"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        calls = int(r.stdout.split("callback calls")[1])
+        # the oracle with the same callback
+        CB = ctypes.CFUNCTYPE(ctypes.c_float, ctypes.c_float, ctypes.c_void_p)
+        seen = []
+
+        def halve(rng, _):
+            seen.append(rng)
+            return rng * 0.5
+        cb = CB(halve)
+        st = L.orc_a52_init()
+        buf = np.zeros(frames.size + 64, np.uint8)
+        buf[:frames.size] = frames.reshape(-1)
+        want = []
+        for f in range(frames.shape[0]):
+            fl, lv = H.ci(flags), H.cf(1.0)
+            assert L.orc_a52_frame(st, ctypes.cast(buf.ctypes.data + f * fb, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0) == 0
+            L.orc_a52_dynrng(st, ctypes.cast(cb, ctypes.c_void_p), None)
+            nout = H.NFCHANS[fl.value & 15] + (1 if fl.value & 16 else 0)
+            for b in range(6):
+                assert L.orc_a52_block(st) == 0
+                want.append(np.ctypeslib.as_array(L.orc_a52_samples(st), (1536,))[:nout * 256].copy())
+        L.orc_a52_free(st)
+        want = np.concatenate(want)
+        got = np.fromfile(tmp_path / "o.f32", np.float32)
+        assert calls == len(seen) and calls > 0, (calls, len(seen))
+        err = got.astype(np.float64) - want
+        scale = max(1.0, H.rms(want))
+        assert H.rms(err) <= 1e-6 * scale, (acmod, H.rms(err), scale)
+        # and it differs from the decode without the callback (the words do something)
+        plain = H.orc_decode(frames, flags, 1.0, 0.0)[0].reshape(-1)
+        assert H.rms(plain - want) > 1e-4 * scale
