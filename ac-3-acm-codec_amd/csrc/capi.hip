@@ -643,12 +643,13 @@ static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_p
 // one workgroup per stream (decode_wg.hip)?  Its eight wavefronts cut the latency of a frame to a third (64 - 256 one-frame
 // streams: 0.09 ms against 0.24 ms) and nothing but the frame and the PCM touches HBM, but a workgroup's wavefronts wait for
 // each other at the block's barriers, so the chip holds fewer busy wavefronts than with one wavefront per stream: measured
-// on one-frame streams it is ahead up to about 2 000 streams (1 024: 0.20 against 0.26 ms; 4 096: 0.57 against 0.40 ms;
-// 65 536: 8.8 against 4.4 ms).  auto: batches of up to 2 048 streams of at most four frames; mode 3 forces it.
+// on one-frame streams it is ahead up to about 1 500 streams (256: 0.086 against 0.23 ms; 1 024: 0.19 against 0.26 ms;
+// 2 048: 0.36 against 0.26 ms; 65 536: 10.7 against 4.4 ms).  auto: batches of up to 1 024 streams of at most four frames;
+// mode 3 forces it.
 static bool use_wg_kernel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
     if (ctx->decode_mode) return ctx->decode_mode == 3;
-    return n_streams <= 2048 && frames_per_stream <= 4;
+    return n_streams <= 1024 && frames_per_stream <= 4;
 }
 
 static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)

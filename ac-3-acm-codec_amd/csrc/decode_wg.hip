@@ -41,8 +41,10 @@ namespace wg {
 
 constexpr int N_WAVES = 8;
 #ifndef WG_LB
-#define WG_LB 6                             // waves per SIMD the register budget is set for (512-thread blocks: 2 per block):
-                                            // 80 VGPRs, three workgroups per CU; measured 4 / 6 / 8: 10.3 / 8.8 / 11.7 ms per 65 536 frames
+#define WG_LB 4                             // waves per SIMD the register budget is set for (512-thread blocks: 2 per block):
+                                            // 128 VGPRs, two workgroups per CU, practically no spills.  6 (80 VGPRs, three per CU)
+                                            // spills: 0.199 / 0.326 / 8.9 ms per 1 024 / 2 048 / 65 536 one-frame streams against
+                                            // 0.186 / 0.358 / 10.7 ms, and its scratch traffic is 4 x the frame's own bytes
 #endif
 constexpr int W_LFE = 5, W_PARSE = 6, W_XFORM = 7;
 constexpr int PLANE = 272;                  // plane pitch in floats: 8-lane groups of the transformer hit different banks
@@ -207,7 +209,7 @@ struct ParserState {
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
-__device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, const BlkInfo &prev, int blk, int lane, const DecodeParams &P, size_t fidx,
+__device__ __forceinline__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, const BlkInfo &prev, int blk, int lane, const DecodeParams &P, size_t fidx,
                               unsigned long long *dbg = nullptr)
 {
     PSTAMP(0);
@@ -353,7 +355,7 @@ __device__ void parse_block_a(const FrameBits FB, ParserState &S, BlkInfo &B, co
 }
 
 // ---- second half: bit-allocation parameters, delta bit allocation, skip field (parse.c:738-772, 800-804) ----
-__device__ void parse_block_b(const FrameBits FB, ParserState &S, BlkInfo &B, int8_t (*deltba)[52], int blk, int lane)
+__device__ __forceinline__ void parse_block_b(const FrameBits FB, ParserState &S, BlkInfo &B, int8_t (*deltba)[52], int blk, int lane)
 {
     VRd rd = make_reader(FB, (uint32_t)ldsu((const int &)S.pos), lane);
     const int nf = ldsu(S.nf), lfeon = ldsu(S.lfeon), chincpl = ldsu(S.chincpl), acmod = ldsu(S.acmod);
@@ -442,7 +444,7 @@ __device__ void parse_block_b(const FrameBits FB, ParserState &S, BlkInfo &B, in
 
 // ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205): frame header and BSI; returns false for a frame the
 // batch cannot hold (no sync word, other channel configuration, too long, an output liba52 would refuse) ----
-__device__ bool parse_frame_header(const FrameBits FB, const uint32_t *frw, ParserState &S, uint16_t *hth, const DecodeParams &P, int lane)
+__device__ __forceinline__ bool parse_frame_header(const FrameBits FB, const uint32_t *frw, ParserState &S, uint16_t *hth, const DecodeParams &P, int lane)
 {
     const uint32_t w0 = rfl(frw[0]), w1 = rfl(frw[1]);
     const int b4 = (w1 >> 24) & 0xff, b5 = (w1 >> 16) & 0xff, b6 = (w1 >> 8) & 0xff;
@@ -506,7 +508,7 @@ __device__ bool parse_frame_header(const FrameBits FB, const uint32_t *frw, Pars
 
 
 // ---- T1 of one slot: exponents, bit allocation, census --------------------------------------------------------------
-__device__ void slot_t1(WgLDS &L, const BlkInfo &B, const FrameBits FB, int slot, int wave, int lane)
+__device__ __forceinline__ void slot_t1(WgLDS &L, const BlkInfo &B, const FrameBits FB, int slot, int wave, int lane)
 {
     const int halfrate = ldsu(B.halfrate);
     const int es = ldsu(B.expstr[slot]);
@@ -587,7 +589,7 @@ __device__ __forceinline__ int openers(int phase, int n, int per)     // members
     return (phase + n + per - 1) / per - (phase + per - 1) / per;
 }
 
-__device__ SegBase segment_prefix(const WgLDS &L, const BlkInfo &B, int slot, int nf, bool lfeon, int lane)
+__device__ __forceinline__ SegBase segment_prefix(const WgLDS &L, const BlkInfo &B, int slot, int nf, bool lfeon, int lane)
 {
     const int chincpl = ldsu(B.chincpl), dithmask = ldsu(B.dithmask);
     const int cplfirst = chincpl ? __builtin_ctz(chincpl) : 99;

@@ -11,7 +11,10 @@
 #include "../../include/ac3mi_stream.h"
 #include "a52_levels.h"
 
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string.h>
 #include <thread>
 #include <tuple>
@@ -85,21 +88,78 @@ int frame_bytes_for(int kbps, uint32_t rate)
 
 enum Stop { STOP_DONE = 0, STOP_DECODE = 1, STOP_ENCODE = 2 };
 
-// the per-stream host work (buffering state machines, staging copies) is independent per stream
+// The per-stream host work (buffering state machines, staging copies) is independent per stream: a pool of worker
+// threads that lives as long as the library, woken per call (thread creation per call cost more than the work of a
+// round of a few thousand streams).
+class Workers {
+public:
+    static Workers &get() { static Workers w; return w; }
+    int threads() const { return (int)th_.size() + 1; }
+    void run(int n, const std::function<void(int, int)> &range)       // range(lo, hi) on every worker and the caller
+    {
+        std::lock_guard<std::mutex> one_at_a_time(run_mu_);
+        const int nt = threads();
+        const int per = (n + nt - 1) / nt;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &range;
+            n_ = n;
+            per_ = per;
+            pending_ = (int)th_.size();
+            generation_++;
+        }
+        cv_.notify_all();
+        range(0, per < n ? per : n);                                    // the caller takes the first share
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    Workers()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nt = (int)(hw ? hw : 1);
+        if (nt > 16) nt = 16;
+        for (int t = 1; t < nt; t++) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~Workers()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; generation_++; }
+        cv_.notify_all();
+        for (auto &x : th_) x.join();
+    }
+    void loop(int t)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *job;
+            int n, per;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                job = job_; n = n_; per = per_;
+            }
+            const int a = t * per, b = a + per < n ? a + per : n;
+            if (job && a < b) (*job)(a, b);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    int n_ = 0, per_ = 0, pending_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+
 template <class F> void parallel_for(int n, F f)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)(hw ? hw : 1);
-    if (nt > 16) nt = 16;
-    if (n < 512 || nt < 2) { for (int i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    const int per = (n + nt - 1) / nt;
-    for (int t = 0; t < nt; t++) {
-        const int a = t * per, b = a + per < n ? a + per : n;
-        if (a >= b) break;
-        th.emplace_back([=] { for (int i = a; i < b; i++) f(i); });
-    }
-    for (auto &x : th) x.join();
+    if (n < 512 || Workers::get().threads() < 2) { for (int i = 0; i < n; i++) f(i); return; }
+    Workers::get().run(n, [&](int lo, int hi) { for (int i = lo; i < hi; i++) f(i); });
 }
 
 }  // namespace
@@ -142,6 +202,7 @@ struct ac3mi_stream {
     uint8_t *dst_p;
     long src_left, dst_left;
     int phase;                      // 0 = entry, 1 = main loop, 2 = resume after a batch, 3 = finished
+    unsigned long long round_tag;   // the ac3mi_stream_convert_many call that last took this stream (a stream may appear once per call)
     // hand-over to / from the batch step
     int req_flags, acmod, lfeon, frame_bytes, granted, fs_next;
     uint32_t status;
@@ -359,19 +420,25 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
         // the frame still advances the stream's dither / overlap state in the reference; it cannot be reproduced
         return AC3MI_MMSYSERR_NOERROR;
     }
+    // frames packed at their own size (rounded up to 4): what crosses PCIe is what the streams sent.  The staging regions of
+    // the groups of a round do not overlap: a group of k streams owns k * FRAME_STRIDE bytes from its base.
+    const int fstride = (s0->frame_bytes + 3) & ~3;
     parallel_for(k, [&](int i) {
         h_slots[i] = group[i]->slot;
-        memcpy(h_frames + (size_t)i * FRAME_STRIDE, group[i]->bufptr, (size_t)s0->frame_bytes);
+        memcpy(h_frames + (size_t)i * fstride, group[i]->bufptr, (size_t)s0->frame_bytes);
     });
-    if (ac3mi_memcpy_h2d(ctx, d_slots, h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_h2d(ctx, d_frames, h_frames, (size_t)k * FRAME_STRIDE) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    // one queue, one wait: slots and frames in, kernels, samples and verdicts out
+    const size_t blk = (size_t)256 * n_out * 2;
+    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_frames, h_frames, (size_t)k * fstride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     ac3mi_set_state_slots(ctx, d_slots);
-    int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames, FRAME_STRIDE, k, 1, p->d_delay, p->d_lfsr, d_s16, d_status);
+    int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames, fstride, k, 1, p->d_delay, p->d_lfsr, d_s16, d_status);
     ac3mi_set_state_slots(ctx, NULL);
     if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch");
-    const size_t blk = (size_t)256 * n_out * 2;
-    if (ac3mi_memcpy_d2h(ctx, h_s16, d_s16, (size_t)k * 6 * blk) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_d2h(ctx, h_status, d_status, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (hipMemcpyAsync(h_s16, d_s16, (size_t)k * 6 * blk, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(h_status, d_status, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
     for (int i = 0; i < k; i++) {
         ac3mi_stream *st = group[i];
@@ -404,18 +471,20 @@ int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
         h_slots[i] = group[i]->slot;
         memcpy(h_in + (size_t)i * in_bytes, group[i]->buf, in_bytes);
     });
-    if (ac3mi_memcpy_h2d(ctx, d_slots, h_slots, (size_t)k * 4) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_memcpy_h2d(ctx, d_s16, h_in, (size_t)k * in_bytes) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_s16, h_in, (size_t)k * in_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     ac3mi_set_state_slots(ctx, d_slots);
     const int rc = ac3mi_encode_batch(ctx, &d, d_s16, chmap, p->d_last, p->d_csnr, d_frames, stride, k, 1, NULL);
     ac3mi_set_state_slots(ctx, NULL);
     if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "encode batch");
-    if (ac3mi_memcpy_d2h(ctx, h_frames, d_frames, (size_t)k * stride) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    if (hipMemcpyAsync(h_frames, d_frames, (size_t)k * stride, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
-    for (int i = 0; i < k; i++) {
+    parallel_for(k, [&](int i) {
         memcpy(group[i]->frame, h_frames + (size_t)i * stride, (size_t)fb);
         group[i]->frame_bytes = fb;
-    }
+    });
     return AC3MI_MMSYSERR_NOERROR;
 }
 
@@ -641,11 +710,14 @@ int ac3mi_stream_convert_many(ac3mi_stream *const *streams, ac3mi_stream_header 
     if (n <= 0) return AC3MI_MMSYSERR_NOERROR;
     if (!streams || !hdrs) return AC3MI_MMSYSERR_INVALPARAM;
     ac3mi_pool *pool = nullptr;
+    static unsigned long long round_counter = 0;
+    const unsigned long long tag = ++round_counter;
     for (int i = 0; i < n; i++) {
         if (!streams[i] || !hdrs[i] || (hdrs[i]->src_len && !hdrs[i]->src) || (hdrs[i]->dst_len && !hdrs[i]->dst)) return AC3MI_MMSYSERR_INVALPARAM;
         if (pool && streams[i]->pool != pool) return AC3MI_MMSYSERR_INVALPARAM;
         pool = streams[i]->pool;
-        for (int j = 0; j < i; j++) if (streams[j] == streams[i]) return AC3MI_MMSYSERR_INVALPARAM;
+        if (streams[i]->round_tag == tag) return AC3MI_MMSYSERR_INVALPARAM;       // the same stream twice in one call
+        streams[i]->round_tag = tag;
         streams[i]->hdr = hdrs[i];
         streams[i]->phase = 0;
     }

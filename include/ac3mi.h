@@ -115,7 +115,7 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
  *      state each frame starts from, then one wavefront per frame decodes them all at once;
  *   3  one 512-thread workgroup per stream: a wavefront per channel beside a parser and a transformer wavefront, the
  *      coefficient planes stay in LDS and the transform is fused in (a third of the latency of variant 1 per frame,
- *      no plane traffic in HBM; ahead for batches of up to about 2 000 streams);
+ *      no plane traffic in HBM; ahead for batches of up to about 1 500 streams);
  *   0  (default) choose by batch shape.
  * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
  * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and
