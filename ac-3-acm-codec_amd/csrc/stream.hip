@@ -11,6 +11,8 @@
 #include "../../include/ac3mi_stream.h"
 #include "a52_levels.h"
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -87,6 +89,31 @@ int frame_bytes_for(int kbps, uint32_t rate)
 }
 
 enum Stop { STOP_DONE = 0, STOP_DECODE = 1, STOP_ENCODE = 2 };
+constexpr int MAX_CHUNKS = 8;
+// AC3MI_STREAM_TRACE=1: wall-clock split of ac3mi_stream_convert_many on stderr (per call), a measurement aid
+struct Trace {
+    bool on = getenv("AC3MI_STREAM_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { auto t = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(t - t0).count(); t0 = t; } }
+    void report() {
+        if (!on) return;
+        fprintf(stderr, "ac3mi_stream_convert_many: machines %.2f + %.2f  grouping %.2f  staging %.2f  issue %.2f ms\n", acc[0], acc[5], acc[1], acc[2], acc[3]);
+        for (double &a : acc) a = 0;
+    }
+};
+Trace g_trace;
+
+// a round's batch crosses PCIe in chunks of about 1 024 streams (AC3MI_STREAM_CHUNKS overrides: measurement aid)
+int chunks_for(int k)
+{
+    static const int forced = getenv("AC3MI_STREAM_CHUNKS") ? atoi(getenv("AC3MI_STREAM_CHUNKS")) : 0;
+    int n = forced > 0 ? forced : k / 1024;
+    if (n > k) n = k;
+    if (n < 1) n = 1;
+    return n > MAX_CHUNKS ? MAX_CHUNKS : n;
+}
 
 // The per-stream host work (buffering state machines, staging copies) is independent per stream: a pool of worker
 // threads that lives as long as the library, woken per call (thread creation per call cost more than the work of a
@@ -95,21 +122,18 @@ class Workers {
 public:
     static Workers &get() { static Workers w; return w; }
     int threads() const { return (int)th_.size() + 1; }
-    void run(int n, const std::function<void(int, int)> &range)       // range(lo, hi) on every worker and the caller
+    // share(t, nt): worker t of nt takes the items of its share; the caller is worker 0
+    void run(const std::function<void(int, int)> &share)
     {
         std::lock_guard<std::mutex> one_at_a_time(run_mu_);
-        const int nt = threads();
-        const int per = (n + nt - 1) / nt;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            job_ = &range;
-            n_ = n;
-            per_ = per;
+            job_ = &share;
             pending_ = (int)th_.size();
             generation_++;
         }
         cv_.notify_all();
-        range(0, per < n ? per : n);                                    // the caller takes the first share
+        share(0, threads());
         std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [&] { return pending_ == 0; });
         job_ = nullptr;
@@ -133,16 +157,14 @@ private:
         unsigned long long seen = 0;
         for (;;) {
             const std::function<void(int, int)> *job;
-            int n, per;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
                 if (stop_) return;
-                job = job_; n = n_; per = per_;
+                job = job_;
             }
-            const int a = t * per, b = a + per < n ? a + per : n;
-            if (job && a < b) (*job)(a, b);
+            if (job) (*job)(t, threads());
             std::lock_guard<std::mutex> lk(mu_);
             if (--pending_ == 0) done_.notify_one();
         }
@@ -151,7 +173,7 @@ private:
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)> *job_ = nullptr;
-    int n_ = 0, per_ = 0, pending_ = 0;
+    int pending_ = 0;
     unsigned long long generation_ = 0;
     bool stop_ = false;
 };
@@ -159,7 +181,12 @@ private:
 template <class F> void parallel_for(int n, F f)
 {
     if (n < 512 || Workers::get().threads() < 2) { for (int i = 0; i < n; i++) f(i); return; }
-    Workers::get().run(n, [&](int lo, int hi) { for (int i = lo; i < hi; i++) f(i); });
+    // shares are block-cyclic (16 items a block): every worker walks the whole index range in order, so when the items
+    // become ready in index order (the chunks of decode_group) all workers start early and finish together
+    Workers::get().run([&](int t, int nt) {
+        for (int lo = t * 16; lo < n; lo += nt * 16)
+            for (int i = lo, hi = lo + 16 < n ? lo + 16 : n; i < hi; i++) f(i);
+    });
 }
 
 }  // namespace
@@ -179,6 +206,9 @@ struct ac3mi_pool {
     uint8_t *d_frames, *h_frames;       // [cap][FRAME_STRIDE]
     int16_t *d_s16, *h_s16;             // [cap][6][256][6]  (decode out)  /  [cap][1536][6] (encode in)
     uint32_t *d_status, *h_status;      // [cap]
+    // decode_group's chunk pipeline: front end + transform of chunk c done / its samples on the host
+    hipEvent_t ev_kernel[MAX_CHUNKS], ev_host[MAX_CHUNKS], ev_join;
+    std::atomic<int> host_seen[MAX_CHUNKS];
 };
 
 struct ac3mi_stream {
@@ -196,6 +226,9 @@ struct ac3mi_stream {
     int flags;                      // msd->flags
     int16_t pcm[6][256 * 6];        // decode: blocks of the current frame that are still owed, interleaved for dst.channels
     const uint8_t *pcm_cur;         // where the current frame's six blocks are: the pool's staging right after a batch, else pcm
+    hipEvent_t pcm_ready;           // set by decode_group: the copy that fills pcm_cur / status_src is still in flight
+    std::atomic<int> *pcm_seen;     // ... and the flag the first stream to see that event finished raises for the rest of its chunk
+    const uint32_t *status_src;
     // per-call locals of the reference's functions, kept across stops
     ac3mi_stream_header *hdr;
     const uint8_t *src_p;
@@ -247,6 +280,16 @@ Stop run_decode(ac3mi_stream *st)
     }
     if (st->phase == 2) {
         // back from a52_frame: hand out the blocks (:1574-1586)
+        if (st->pcm_ready) {
+            // the batch's samples come over in chunks; this stream's chunk may still be on its way
+            if (!st->pcm_seen->load(std::memory_order_acquire)) {
+                if (hipEventSynchronize(st->pcm_ready) != hipSuccess) { memset(st->pcm, 0, sizeof st->pcm); st->pcm_cur = (const uint8_t *)st->pcm; }
+                else st->pcm_seen->store(1, std::memory_order_release);
+            }
+            st->pcm_ready = nullptr;
+            st->status = *st->status_src;
+            st->granted = (int)((st->status >> 16) & 0xff);
+        }
         st->phase = 1;
         st->bufptr = st->bufend = st->buf;
         sr = 512 * nch;
@@ -427,25 +470,45 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
         h_slots[i] = group[i]->slot;
         memcpy(h_frames + (size_t)i * fstride, group[i]->bufptr, (size_t)s0->frame_bytes);
     });
-    // one queue, one wait: slots and frames in, kernels, samples and verdicts out
+    g_trace.lap(2);
+    // the batch runs in chunks of whole streams on the context's stream (frames in, kernels) while a second stream brings
+    // each finished chunk's samples over: 18 KB per frame across PCIe is the longest
+    // leg of a round, and the state machines take a chunk's blocks (run_decode waits on ev_host) while the next is on its way
     const size_t blk = (size_t)256 * n_out * 2;
-    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(d_frames, h_frames, (size_t)k * fstride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    ac3mi_set_state_slots(ctx, d_slots);
-    int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames, fstride, k, 1, p->d_delay, p->d_lfsr, d_s16, d_status);
-    ac3mi_set_state_slots(ctx, NULL);
-    if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch");
-    if (hipMemcpyAsync(h_s16, d_s16, (size_t)k * 6 * blk, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(h_status, d_status, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
-    for (int i = 0; i < k; i++) {
-        ac3mi_stream *st = group[i];
-        st->status = h_status[i];
-        st->granted = (int)((st->status >> 16) & 0xff);
-        st->pcm_cur = (const uint8_t *)h_s16 + (size_t)i * 6 * blk;      // handed out (or saved) by run_decode before the next batch
+    const int n_chunks = chunks_for(k);
+    for (int c = 0; c < n_chunks; c++) {
+        const int lo = (int)((long long)k * c / n_chunks), hi = (int)((long long)k * (c + 1) / n_chunks), kc = hi - lo;
+        p->host_seen[c].store(0, std::memory_order_relaxed);
+        if (hipMemcpyAsync(d_frames + (size_t)lo * fstride, h_frames + (size_t)lo * fstride, (size_t)kc * fstride, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+        }
+        ac3mi_set_state_slots(ctx, d_slots + lo);
+        const int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames + (size_t)lo * fstride, fstride, kc, 1, p->d_delay, p->d_lfsr,
+                                              (int16_t *)((uint8_t *)d_s16 + (size_t)lo * 6 * blk), d_status + lo);
+        ac3mi_set_state_slots(ctx, NULL);
+        if (rc != AC3MI_OK) { (void)hipDeviceSynchronize(); return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch"); }
+        if (hipEventRecord(p->ev_kernel[c], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, p->ev_kernel[c], 0) != hipSuccess ||
+            hipMemcpyAsync((uint8_t *)h_s16 + (size_t)lo * 6 * blk, (uint8_t *)d_s16 + (size_t)lo * 6 * blk, (size_t)kc * 6 * blk, hipMemcpyDeviceToHost, ctx->stream2) != hipSuccess ||
+            hipMemcpyAsync(h_status + lo, d_status + lo, (size_t)kc * 4, hipMemcpyDeviceToHost, ctx->stream2) != hipSuccess ||
+            hipEventRecord(p->ev_host[c], ctx->stream2) != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+        }
+        for (int i = lo; i < hi; i++) {
+            ac3mi_stream *st = group[i];
+            st->pcm_cur = (const uint8_t *)h_s16 + (size_t)i * 6 * blk;      // handed out (or saved) by run_decode before the next batch
+            st->status_src = h_status + i;
+            st->pcm_ready = p->ev_host[c];
+            st->pcm_seen = &p->host_seen[c];
+        }
     }
+    // the next call on this context (and the next round's staging writes) must find the second stream idle as well
+    if (hipEventRecord(p->ev_join, ctx->stream2) != hipSuccess || hipStreamWaitEvent(ctx->stream, p->ev_join, 0) != hipSuccess)
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    g_trace.lap(3);
     return AC3MI_MMSYSERR_NOERROR;
 }
 
@@ -471,13 +534,25 @@ int encode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
         h_slots[i] = group[i]->slot;
         memcpy(h_in + (size_t)i * in_bytes, group[i]->buf, in_bytes);
     });
-    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(d_s16, h_in, (size_t)k * in_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    // the samples (18 KB per frame) cross PCIe in chunks on the second stream while the context's stream encodes the chunk before
+    if (hipMemcpyAsync(d_slots, h_slots, (size_t)k * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
-    ac3mi_set_state_slots(ctx, d_slots);
-    const int rc = ac3mi_encode_batch(ctx, &d, d_s16, chmap, p->d_last, p->d_csnr, d_frames, stride, k, 1, NULL);
-    ac3mi_set_state_slots(ctx, NULL);
-    if (rc != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "encode batch");
+    if (hipEventRecord(p->ev_join, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, p->ev_join, 0) != hipSuccess)      // earlier work on this staging
+        return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+    const int n_chunks = chunks_for(k);
+    for (int c = 0; c < n_chunks; c++) {
+        const int lo = (int)((long long)k * c / n_chunks), hi = (int)((long long)k * (c + 1) / n_chunks), kc = hi - lo;
+        if (hipMemcpyAsync((uint8_t *)d_s16 + (size_t)lo * in_bytes, h_in + (size_t)lo * in_bytes, (size_t)kc * in_bytes, hipMemcpyHostToDevice, ctx->stream2) != hipSuccess ||
+            hipEventRecord(p->ev_kernel[c], ctx->stream2) != hipSuccess || hipStreamWaitEvent(ctx->stream, p->ev_kernel[c], 0) != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
+        }
+        ac3mi_set_state_slots(ctx, d_slots + lo);
+        const int rc = ac3mi_encode_batch(ctx, &d, (const int16_t *)((const uint8_t *)d_s16 + (size_t)lo * in_bytes), chmap, p->d_last, p->d_csnr,
+                                          d_frames + (size_t)lo * stride, stride, kc, 1, NULL);
+        ac3mi_set_state_slots(ctx, NULL);
+        if (rc != AC3MI_OK) { (void)hipDeviceSynchronize(); return fail(p, AC3MI_MMSYSERR_NOMEM, "encode batch"); }
+    }
     if (hipMemcpyAsync(h_frames, d_frames, (size_t)k * stride, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
     if (ac3mi_sync(ctx) != AC3MI_OK) return fail(p, AC3MI_MMSYSERR_NOMEM, "sync");
@@ -517,6 +592,9 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
     p->h_frames = (uint8_t *)pin(n * FRAME_STRIDE);
     p->h_s16 = (int16_t *)pin(n * PCM_FRAME_BYTES);
     p->h_status = (uint32_t *)pin(n * 4);
+    for (int c = 0; c < MAX_CHUNKS; c++)
+        ok = ok && hipEventCreateWithFlags(&p->ev_kernel[c], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&p->ev_host[c], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
     if (ok) {
         // every slot starts as a52_init (delay 0, lfsr 1, L52/parse.c:75) and AC3_encode_init (history 0, csnroffst 40,
         // ENC/ac3enc.cpp:1092) leave a new stream
@@ -539,6 +617,11 @@ void ac3mi_pool_destroy(ac3mi_pool *p)
     for (void *q : dv) if (q) ac3mi_dev_free(p->ctx, q);
     void *hv[] = {p->h_slots, p->h_frames, p->h_s16, p->h_status};
     for (void *q : hv) if (q) (void)hipHostFree(q);
+    for (int c = 0; c < MAX_CHUNKS; c++) {
+        if (p->ev_kernel[c]) (void)hipEventDestroy(p->ev_kernel[c]);
+        if (p->ev_host[c]) (void)hipEventDestroy(p->ev_host[c]);
+    }
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     delete p;
 }
 
@@ -723,25 +806,41 @@ int ac3mi_stream_convert_many(ac3mi_stream *const *streams, ac3mi_stream_header 
     }
     if (hipSetDevice(pool->ctx->device) != hipSuccess) return AC3MI_MMSYSERR_NOMEM;
     typedef std::tuple<int, int, int, int, int, int> Key;
+    bool first_pass = true;
     for (;;) {
         std::map<Key, std::vector<ac3mi_stream *>> dec, enc;
         std::vector<int> stops((size_t)n, STOP_DONE);
+        g_trace.start();
         parallel_for(n, [&](int i) {
             ac3mi_stream *st = streams[i];
             if (st->phase != 3) stops[(size_t)i] = st->decode ? run_decode(st) : run_encode(st);
         });
+        g_trace.lap(first_pass ? 0 : 5);
+        first_pass = false;
+        // (neighbours in the caller's array mostly share a configuration: the last group found is tried first)
+        Key last_key(-1, -1, -1, -1, -1, -1);
+        std::vector<ac3mi_stream *> *last_group = nullptr;
         for (int i = 0; i < n; i++) {
             ac3mi_stream *st = streams[i];
-            if (stops[(size_t)i] == STOP_DECODE)
-                dec[Key(st->acmod, st->lfeon, st->frame_bytes, st->req_flags, (int)(st->driver_flags & AC3MI_ACM_DYNAMICRANGE), st->dst.channels)].push_back(st);
-            else if (stops[(size_t)i] == STOP_ENCODE)
-                enc[Key(st->enc_rate, st->enc_bitrate, st->src.channels, 0, 0, 0)].push_back(st);
+            const int stop = stops[(size_t)i];
+            if (stop == STOP_DONE) continue;
+            const Key key = stop == STOP_DECODE
+                ? Key(st->acmod, st->lfeon, st->frame_bytes, st->req_flags, (int)(st->driver_flags & AC3MI_ACM_DYNAMICRANGE), st->dst.channels)
+                : Key(st->enc_rate, st->enc_bitrate, st->src.channels, -2, 0, 0);
+            if (!last_group || key != last_key) {
+                last_group = stop == STOP_DECODE ? &dec[key] : &enc[key];
+                last_key = key;
+                if (last_group->empty()) last_group->reserve((size_t)n);
+            }
+            last_group->push_back(st);
         }
+        g_trace.lap(1);
         if (dec.empty() && enc.empty()) break;
         int base = 0;
         for (auto &g : dec) { const int rc = decode_group(pool, g.second, base); if (rc) return rc; base += (int)g.second.size(); }
         for (auto &g : enc) { const int rc = encode_group(pool, g.second, base); if (rc) return rc; base += (int)g.second.size(); }
     }
+    g_trace.report();
     return AC3MI_MMSYSERR_NOERROR;
 }
 
