@@ -58,6 +58,7 @@ ALG = {
     "xform_kernel<false, 4, false>": 36864 + 36864 + 6144,
     "xform_kernel<false, 3, true>": 36864 + 18432 + 6144,
     "xform_kernel<true, 2, false>": 30720 + 12288 + 2048,
+    "xform_kernel<true, 3, false>": 30720 + 12288 + 2048,
     "decode_kernel<0>": 1536 + 36864,
     "decode_wg_kernel<0>": 1536 + 36864,
     "decode_wg_kernel<1>": 1536 + 36864 + 6144,
@@ -108,7 +109,7 @@ legs = {
     "decode": pick("decode_kernel<0>", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
     "decode_s16": pick("decode_kernel<0>", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
     "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>"),
-    "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>"),
+    "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>", "xform_kernel<true, 3, false>"),
 }
 legs["transcode"] = sorted(set(legs["decode_s16"]) | set(legs["encode"]))
 json.dump({"frames_per_launch": frames, "kernels": kern, "legs": legs,
