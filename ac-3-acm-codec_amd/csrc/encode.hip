@@ -82,8 +82,11 @@ struct MaskTabs {
 
 struct alignas(16) PackLDS {
     int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
-    uint32_t gtab[128];         // 3/5/11-level codes being assembled, rings of 32 / 32 / 64: bit offset | 16-bit code << 16
+    uint32_t gtab[640];         // 3/5/11-level codes being assembled, rings of 128 / 128 / 256: bit offset | 16-bit code << 16; from 512 on two
+                                // sink words per lane: where stores, adds and put_bits_always of lanes with nothing to say go
     uint32_t bitlut[64];        // see lut_index
+    uint32_t packlut[64];       // the packing sweep's view of the same address: see pack_word
+    alignas(4) uint8_t erow[256];       // encoded exponents of the channel whose exponent groups are being packed
     // (the frame itself, MSB-first dwords + 256 bytes of headroom for the overshoot quirk, is dynamic LDS: PackParams::frw)
     int8_t shiftv[36];          // exp_samples of the frame
     uint8_t strat[6][6];
@@ -697,6 +700,17 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
 // bap of one coefficient for SNR offset `snroffset` (:393-420):
 //   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
 //   =>  address = clamp(80 - 4 exp - max(0, (mask - floor - snroffset) >> 5), 0, 63)       (floor = 0x1f0)
+// the same without a branch: a field of no bits (or outside the frame) goes to the lane's own sink words (atomics of a
+// whole wavefront on ONE address would be served one lane after the other)
+__device__ __forceinline__ void put_bits_always(uint32_t *fr, int frw, uint32_t *sink, uint32_t pos, int n, uint32_t v)
+{
+    const int n_in = (pos >> 5) + 1 < (uint32_t)frw ? n : 0;
+    uint32_t *dst = n_in > 0 ? fr + (pos >> 5) : sink;
+    const uint64_t x = (uint64_t)v << ((64 - n - (int)(pos & 31)) & 63);
+    atomicOr(dst, (uint32_t)(x >> 32));
+    atomicOr(dst + 1, (uint32_t)x);
+}
+
 // L.bitlut[address] = plain mantissa width | (bap==1) << 10 | (bap==2) << 16 | (bap==4) << 22 | bap << 28.
 // lut_index returns the address with d4 = 4 * (80 - 4 exp) (hugely negative for a padding item: address 0,
 // bap 0, no bits).
@@ -714,6 +728,21 @@ __device__ __forceinline__ int lut_index(int d4, int mask_minus_floor, int snrof
 __device__ __forceinline__ int plain_bits(int bp)
 {
     return bp == 3 ? 3 : bp == 5 ? 4 : bp == 14 ? 14 : bp == 15 ? 16 : bp >= 6 ? bp - 1 : 0;
+}
+
+// What the packing sweep needs to know about a bap code, as fields of one word, so that the sweep is integer arithmetic on
+// registers instead of compares (every combined per-lane condition costs scalar mask instructions):
+//   0-4 plain bits   5-6 kind (0/1/2 = member of a 3-/5-/11-level code, 3 = not grouped)   7-9 bits of a grouped code
+//   10-13 levels of the symmetric quantiser   14 symmetric   15-19 weight of a code's first member   20-23 bap
+//   24-28 10 * kind (position of the kind's counter in the packed rank word)
+__device__ __forceinline__ uint32_t pack_word(int bp)
+{
+    const uint32_t kind = bp == 1 ? 0u : bp == 2 ? 1u : bp == 4 ? 2u : 3u;
+    const uint32_t gbits = kind == 0 ? 5u : kind < 3 ? 7u : 0u;
+    const uint32_t levels = bp == 1 ? 3u : bp == 2 ? 5u : bp == 4 ? 11u : bp == 3 ? 7u : 15u;
+    const uint32_t sym = (kind < 3 || bp == 3 || bp == 5) ? 1u : 0u;
+    const uint32_t w0 = kind == 0 ? 9u : kind == 1 ? 25u : kind == 2 ? 11u : 1u;
+    return (uint32_t)plain_bits(bp) | (kind << 5) | (gbits << 7) | (levels << 10) | (sym << 14) | (w0 << 15) | ((uint32_t)bp << 20) | ((10u * kind) << 24);
 }
 
 // The reference's SNR-offset search (:921-967) as a resumable state machine: next() skips the steps that
@@ -768,9 +797,8 @@ __device__ __forceinline__ int quant_sym(int c, int e, int levels)       // :115
 __device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :1169-1190
 {
     const int lshift = e + qbits - 24;
-    int v;
-    if (lshift >= 0) v = (int)((unsigned)c << (lshift & 31));
-    else v = c >> ((-lshift) & 31);
+    const int up = (int)((unsigned)c << (lshift & 31)), down = c >> ((-lshift) & 31);      // both, then a select: no branch
+    int v = lshift >= 0 ? up : down;
     v = (v + 1) >> 1;
     const int m = 1 << (qbits - 1);
     if (v >= m) v = m - 1;
@@ -804,8 +832,29 @@ __device__ uint32_t region_crc(const PackLDS &L, const uint32_t *fr, int end, in
 // frame's own optimum; PART 1 (one wavefront per stream) replays the reference's search sequence frame after frame
 // from those tables - costing an offset itself only when the table has no answer - and leaves csnroffst / fsnroffst
 // of every frame in P.snr; PART 2 (one wavefront per frame) packs all frames at once.
+// Measurement aid (make EXTRA=-DPACK_STAMPS, a separate library): lane 0 of every wavefront adds the s_memtime cycles it
+// spent in each section of a frame to g_pack_cycles: 0 frame set-up + SNR-offset search, 1 header / side information /
+// exponent groups, 2 mantissas, 3 CRCs + store, 4 = calls of cost_and_record, 5 = frames.  ac3mi_debug_pack_cycles reads them.
+#ifdef PACK_STAMPS
+__device__ unsigned long long g_pack_cycles[8];
+#define PK_DECL() unsigned long long pk_t = 0, pk_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PK_T0() pk_t = __builtin_readcyclecounter()
+#define PK_LAP(id) do { const unsigned long long t_ = __builtin_readcyclecounter(); pk_acc[id] += t_ - pk_t; pk_t = t_; } while (0)
+#define PK_COUNT(id) pk_acc[id] += 1
+#define PK_END() do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_pack_cycles[i_], pk_acc[i_]); } while (0)
+#else
+#define PK_DECL() do { } while (0)
+#define PK_T0() do { } while (0)
+#define PK_LAP(id) do { } while (0)
+#define PK_COUNT(id) do { } while (0)
+#define PK_END() do { } while (0)
+#endif
+
+#ifndef ENC_PACK_LB
+#define ENC_PACK_LB 4            // wavefronts per SIMD the packer's register budget is set for (128 VGPRs; at 5 the branch-free mantissa passes spill: 6.26 vs 6.09 ms per 65 536 frames)
+#endif
 template <int PART>
-__global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
     extern __shared__ uint4 pk_dyn[];
@@ -824,19 +873,22 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
     {
         const int bp = P.tab->baptab[lane];
         L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 10) | ((bp == 2) << 16) | ((bp == 4) << 22) | ((uint32_t)bp << 28);
+        L.packlut[lane] = pack_word(bp);
     }
 
     // fixed allocation codes (:861-879)
     const int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
     const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
-    const int T = nfbw * nbc + (P.lfe ? 7 : 0);
     const int fs = P.frame_words;
 
     const int sslot = P.slot ? P.slot[s] : s;
     int csnr_prev = PART == 2 ? 0 : P.csnr_state[sslot];
+    PK_DECL();
 
     for (int f = f_first; f < f_end; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
+        PK_T0();
+        PK_COUNT(5);
         const int32_t *md = P.mdct + fidx * 6 * nch * 256;
         const int8_t *sh = P.shift + fidx * 6 * nch;
 
@@ -869,39 +921,32 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                 for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
             WAVE_SYNC();
 
-            // ---- fixed side information (:880-916) ----
-            {
-                const int extra[8] = {0, 0, 2, 2, 2, 4, 2, 4};
-                frame_bits += 65 + extra[P.acmod & 7];
-                for (int b = 0; b < 6; b++) {
-                    frame_bits += nfbw * 2 + 2;
-                    if (P.acmod == 2) frame_bits++;
-                    frame_bits += 2 * nfbw;
-                    if (P.lfe) frame_bits++;
-                    for (int ch = 0; ch < nfbw; ch++)
-                        if (L.strat[b][ch] != 0) frame_bits += 6 + 2;
-                    frame_bits += 1 + 1 + 2;
-                }
-                frame_bits++;
-                frame_bits += 2 * 4 + 3 + 6 + nch * (4 + 3);
-                frame_bits += 2;
-                frame_bits += 16;
-            }
-
             if (lane < 36) {
                 const int b = lane / 6, ch = lane - 6 * b;
                 L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
             }
             WAVE_SYNC();
-            // bit 8*ch + b: block b sends new exponents for channel ch; rows (blk * 6 + ch) that start a run, as a bit set
-            run_starts = row_set = 0;
-            for (int ch = 0; ch < nch; ch++) {
-                const unsigned long long m = __ballot(lane < 6 && L.strat[lane < 6 ? lane : 0][ch] != 0);
-                run_starts |= (uint64_t)(m & 0x3f) << (8 * ch);
+            // rows (blk * 6 + ch) that send new exponents, i.e. start a run, as a bit set; and the same as bit 8*ch + b
+            {
+                const int b6 = lane / 6, c6 = lane - 6 * b6;
+                row_set = __ballot(lane < 36 && c6 < nch && L.strat[lane < 36 ? b6 : 0][c6] != 0);
+                const int c8 = lane >> 3, b8 = lane & 7;
+                run_starts = __ballot(b8 < 6 && c8 < nch && L.strat[b8 < 6 ? b8 : 0][c8 < 6 ? c8 : 0] != 0);
             }
-            for (int ch = 0; ch < nch; ch++)
-                for (int b = 0; b < 6; b++)
-                    if ((run_starts >> (8 * ch + b)) & 1) row_set |= 1ull << (b * 6 + ch);
+            // ---- fixed side information (:880-916) ----
+            {
+                const int extra[8] = {0, 0, 2, 2, 2, 4, 2, 4};
+                frame_bits += 65 + extra[P.acmod & 7];
+                frame_bits += 6 * (nfbw * 2 + 2 + (P.acmod == 2 ? 1 : 0) + 2 * nfbw + (P.lfe ? 1 : 0) + 1 + 1 + 2);
+                // chbwcod (6 bits) and gainrng (2 bits) of every full-bandwidth channel-block that sends exponents
+                uint64_t fbw_rows = 0;
+                for (int b = 0; b < 6; b++) fbw_rows |= ((1ull << nfbw) - 1) << (6 * b);
+                frame_bits += 8 * __builtin_popcountll(row_set & fbw_rows);
+                frame_bits++;
+                frame_bits += 2 * 4 + 3 + 6 + nch * (4 + 3);
+                frame_bits += 2;
+                frame_bits += 16;
+            }
         };
         // PART 1 replays the search from tabulated verdicts and needs the frame's data only for a verdict that is missing
         if (PART != 1 || P.tap_strat) load_frame();
@@ -939,20 +984,27 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
         // added to the per-lane accumulators of all blocks of the run.
         auto cost_and_record = [&](const int *so, const int *cand_c, const int *cand_f, int n_cand) {
             if (!loaded) load_frame();
+            PK_COUNT(4);
             const int budget = 16 * fs - frame_bits;
             uint32_t acc[6][3];
 #pragma unroll
             for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
             {
                 // one run-start row per step: four bins per lane from one dword (HBM/L2), the next row's dword in flight
+                // (the exponent dwords of the next three rows are in flight while one is costed)
                 uint64_t todo = row_set;
-                int r = __builtin_ctzll(todo);
-                uint32_t ev = *reinterpret_cast<const uint32_t *>(ex + ((size_t)(r / 6) * nch + (r % 6)) * 256 + 4 * lane);
+                auto row_of = [&](uint64_t t, int fallback) { return t ? (int)__builtin_ctzll(t) : fallback; };
+                auto fetch = [&](int row) { return *reinterpret_cast<const uint32_t *>(ex + ((size_t)(row / 6) * nch + (row % 6)) * 256 + 4 * lane); };
+                int r = row_of(todo, 0);
+                uint64_t t1 = todo & (todo - 1), t2 = t1 & (t1 - 1);
+                int r1 = row_of(t1, r), r2 = row_of(t2, r1);
+                uint32_t ev = fetch(r), ev1 = fetch(r1), ev2 = fetch(r2);
 #pragma unroll 1
                 while (todo) {
                     todo &= todo - 1;
-                    const int rn = todo ? __builtin_ctzll(todo) : r;
-                    const uint32_t evn = *reinterpret_cast<const uint32_t *>(ex + ((size_t)(rn / 6) * nch + (rn % 6)) * 256 + 4 * lane);
+                    const uint64_t t3 = t2 & (t2 - 1);
+                    const int r3 = row_of(t3, r2);
+                    const uint32_t ev3 = fetch(r3);
                     const int b0 = r / 6, ch = r - 6 * b0;
                     const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
                     const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
@@ -969,8 +1021,9 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
 #pragma unroll
                     for (int B = 0; B < 6; B++)
                         if (B >= b0 && B < b1) { acc[B][0] += sum[0]; acc[B][1] += sum[1]; acc[B][2] += sum[2]; }
-                    r = rn;
-                    ev = evn;
+                    r = r1; r1 = r2; r2 = r3;
+                    ev = ev1; ev1 = ev2; ev2 = ev3;
+                    t2 = t3;
                 }
             }
             int total[3] = {0, 0, 0};
@@ -1067,12 +1120,33 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
             continue;
         }
 
+        PK_LAP(0);
         // ---- header (:1113-1147) ----
-        uint32_t pos = 0;
+        // Side information is wave-uniform: its fields collect in a 64-bit accumulator that stays in scalar registers and
+        // reach the LDS frame 32 bits at a time (one lane, one put_bits per word instead of one per field); `flush` empties
+        // it before the lanes write at `pos` themselves (exponent groups, mantissas).
+        uint32_t pos = 0;                   // first bit not yet in the frame
+        uint64_t acc = 0;
+        int nacc = 0;                       // pending bits, the low `nacc` of acc
         auto put = [&](int n, uint32_t v) {
-            if (lane == 0) put_bits(fr, P.frw, pos, n, v);
-            pos += n;
+            acc = (acc << n) | v;
+            nacc += n;
+            if (nacc >= 32) {
+                const uint32_t word = (uint32_t)(acc >> (nacc - 32));
+                if (lane == 0) put_bits(fr, P.frw, pos, 32, word);
+                pos += 32;
+                nacc -= 32;
+            }
         };
+        auto flush = [&]() {
+            if (nacc > 0) {
+                const uint32_t word = (uint32_t)acc & (0xffffffffu >> (32 - nacc));
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc, word);
+                pos += nacc;
+                nacc = 0;
+            }
+        };
+        auto uni = [&](int v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); };
         put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
         if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
         if (P.acmod & 4) put(2, 1);
@@ -1081,23 +1155,37 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
 
         // ---- audio blocks (:1194-1502) ----
         for (int b = 0; b < 6; b++) {
+            // this block's encoded exponents, one dword (four bins) per lane and channel, all rows in flight together: the
+            // mantissa passes use them from registers, the exponent groups of a channel through L.erow
+            uint32_t ew[6];
+#pragma unroll
+            for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane) : 0u;
             for (int ch = 0; ch < nfbw; ch++) put(1, 0);
             for (int ch = 0; ch < nfbw; ch++) put(1, 1);
             put(1, 0);
             if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
             if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
-            for (int ch = 0; ch < nfbw; ch++) put(2, L.strat[b][ch]);
-            if (P.lfe) put(1, L.strat[b][nch - 1]);
-            for (int ch = 0; ch < nfbw; ch++) if (L.strat[b][ch] != 0) put(6, P.chbwcod);
+            for (int ch = 0; ch < nfbw; ch++) put(2, uni(L.strat[b][ch]));
+            if (P.lfe) put(1, uni(L.strat[b][nch - 1]));
+            for (int ch = 0; ch < nfbw; ch++) if (uni(L.strat[b][ch]) != 0) put(6, P.chbwcod);
             // exponents: lanes over groups
             for (int ch = 0; ch < nch; ch++) {
-                const int stg = L.strat[b][ch];
+                const int stg = (int)uni(L.strat[b][ch]);
                 if (stg == 0) continue;
                 const bool is_lfe = P.lfe && ch == nch - 1;
                 const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
                 const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
-                const uint8_t *e = ex + ((size_t)b * nch + ch) * 256;
-                put(4, e[0]);
+                const uint8_t *e = &L.erow[0];
+                {
+                    uint32_t row = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; c2++) row = c2 == ch ? ew[c2] : row;      // (no indexing of the register array)
+                    WAVE_SYNC();                                            // the previous channel's groups have read the row
+                    *reinterpret_cast<uint32_t *>(&L.erow[4 * lane]) = row;
+                    WAVE_SYNC();
+                }
+                put(4, uni(e[0]));
+                flush();
                 for (int g = lane; g < ng; g += 64) {
                     const int k0 = 1 + 3 * g * gs;
                     const int prev = g ? e[k0 - gs] : e[0];
@@ -1116,31 +1204,18 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
             }
             put(1, 0);
             put(1, 0);
+            flush();
+            PK_LAP(1);
 
-            // ---- mantissas (:1334-1502): one sweep, 64 consecutive coefficients per step.  Two packed
-            //      wavefront scans per step give every coefficient its rank among the 3/5/11-level codes
-            //      and its bit offset.  A grouped code is assembled in L.gtab (rings of 32 / 32 / 64 slots,
-            //      only the newest group of a kind can be incomplete): the opener stores offset and its
-            //      weighted value, later members add theirs, the last member writes the code out. ----
-            if (P.tap_bap) {
-                uint8_t *tb = P.tap_bap + (fidx * 6 + b) * nch * 256;
-                for (int ch = 0; ch < nch; ch++)
-                    for (int i = lane; i < 256; i += 64) {
-                        const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-                        if (i >= n) tb[ch * 256 + i] = 0;
-                    }
-            }
+            // ---- mantissas (:1334-1502): one pass per channel, four consecutive coefficients per lane, branch-free.
+            //      A lane's counts of 3/5/11-level mantissas travel as one word of 10-bit fields through one wavefront
+            //      scan (ranks -> who opens a grouped code), its bits through a second (offsets).  A grouped code is
+            //      assembled in L.gtab (rings of 128 / 128 / 256 slots per kind: a pass opens at most 86 / 86 / 128 codes
+            //      and one older code per kind can be incomplete): the opener stores offset and its weighted value, later
+            //      members add theirs, the last member writes the code out.  Lanes with nothing to store or add use the
+            //      sink slot / a zero value instead of a branch. ----
             {
-                const uint8_t *Eb = ex + (size_t)b * nch * 256;
-                const int16_t *Mb = &L.mask[b * 6][0];
                 const int32_t *mdb = md + (size_t)b * nch * 256;
-                // step k covers coefficients 64k .. 64k+63 of the block's stream (channel-major, LFE last); the
-                // coefficient and exponent of the next step are already in flight while this one is packed
-                const int R = (T + 63) >> 6;
-                int t_ch = lane / nbc, t_bin = lane - t_ch * nbc;           // lane < 64 <= nbc: channel 0
-                if (nfbw == 0) { t_ch = 0; t_bin = lane; }
-                int nx_coef = lane < T ? mdb[t_ch * 256 + t_bin] : 0;
-                int nx_exp = lane < T ? Eb[t_ch * 256 + t_bin] : 0;
                 // The reference quantises a whole block before it writes it, and does not write a grouped code whose
                 // (out-of-contract, garbage) 16-bit value equals 128: everything after it then sits 5 or 7 bits earlier.
                 // First attempt: nominal offsets; such codes are recorded, not written.  If there were any (practically
@@ -1151,80 +1226,121 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                 if (lane == 0) L.ncoll = 0;
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
-                t_ch = lane / nbc; t_bin = lane - t_ch * nbc;
-                if (nfbw == 0) { t_ch = 0; t_bin = lane; }
-                nx_coef = lane < T ? mdb[t_ch * 256 + t_bin] : 0;
-                nx_exp = lane < T ? Eb[t_ch * 256 + t_bin] : 0;
-                int b3 = 0, b5 = 0, b11 = 0;
+                int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
+                uint32_t baseg = 0, basem = 0;      // the same as (codes opened mod 256) << 8 kind and (members of the open code) << 2 kind
+                int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
+                uint32_t *const sink = &L.gtab[512 + 2 * lane];
 #pragma unroll 1
-                for (int k = 0; k < R; k++) {
-                    const int eo = t_ch * 256 + t_bin;
-                    const bool valid = 64 * k + lane < T;
-                    const int c = nx_coef, xe = nx_exp;
-                    const int m = Mb[t_ch * 50 + L.band_of_bin[t_bin]];
-                    // next step's position and loads
-                    t_bin += 64;
-                    if (t_ch < nfbw && t_bin >= nbc) { t_bin -= nbc; t_ch++; }
+                for (int ch = 0; ch < nch; ch++) {
+                    const int4 c4 = nx_c;
+                    uint32_t e4 = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; c2++) e4 = c2 == ch ? ew[c2] : e4;
                     {
-                        const bool nv = 64 * (k + 1) + lane < T;
-                        const int no = nv ? t_ch * 256 + t_bin : 0;
-                        nx_coef = mdb[no];
-                        nx_exp = Eb[no];
-                        if (!nv) { t_ch = 0; t_bin = 0; }
+                        const int nc = ch + 1 < nch ? ch + 1 : ch;          // the next channel's coefficients are in flight meanwhile
+                        nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
                     }
-                    const int d4 = valid ? 320 - 16 * xe : -(1 << 20);
-                    const uint32_t lut = L.bitlut[lut_index(d4, m, snroffset)];
-                    const int bp = (int)(lut >> 28);
-                    const int e = xe - (int)L.shiftv[b * 6 + (eo >> 8)];
-                    if (P.tap_bap && valid) P.tap_bap[(fidx * 6 + b) * nch * 256 + eo] = (uint8_t)bp;
-
-                    const int kind = bp == 1 ? 0 : bp == 2 ? 1 : bp == 4 ? 2 : -1;
-                    const uint32_t gcnt = kind < 0 ? 0u : 1u << (8 * kind);
-                    const uint32_t gincl = wave_incl_scan_u32(gcnt);
-                    const uint32_t gexcl = gincl - gcnt;
-                    const int rank = kind == 0 ? b3 + (int)(gexcl & 255u)
-                                   : kind == 1 ? b5 + (int)((gexcl >> 8) & 255u)
-                                               : b11 + (int)(gexcl >> 16);
-                    const int grp = kind == 2 ? rank >> 1 : (int)(((uint32_t)rank * 0xaaabu) >> 17);   // rank / 3, rank < 2^15
-                    const int per = kind == 2 ? 2 : 3;
-                    const int mem = rank - grp * per;
-                    const bool grouped = kind >= 0;
-                    const bool opens = grouped && mem == 0;
-                    const int gbits = kind == 0 ? 5 : 7;
-                    const int w = (int)(lut & 0x3ffu);
-                    bool dropped = false;
-                    if (dropped_known) {                             // second attempt only
-                        const uint32_t key = ((uint32_t)kind << 16) | (uint32_t)grp;
-                        for (int q = 0; q < dropped_known; q++) dropped |= opens && L.coll[q] == key;
+                    const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                    const int16_t *Mr = &L.mask[b * 6 + ch][0];
+                    const int shv = (int)L.shiftv[b * 6 + ch];
+                    const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
+                    uint32_t pw[4], cnt_lane = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int xe = (int)((e4 >> (8 * j)) & 0xff), m = Mr[(bandoff >> (8 * j)) & 0xff];
+                        const int d4 = 4 * lane + j < n ? 320 - 16 * xe : -(1 << 20);
+                        pw[j] = L.packlut[lut_index(d4, m, snroffset)];
+                        cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
                     }
-                    const int nb = grouped ? (opens && !dropped ? gbits : 0) : w;
-                    const uint32_t bincl = wave_incl_scan_u32((uint32_t)nb);
-                    const uint32_t off = pos + bincl - (uint32_t)nb;
-                    const uint32_t gtot = wave_last(gincl);
-
-                    // quantise (:1150-1190)
-                    const int levels = bp == 1 ? 3 : bp == 2 ? 5 : bp == 4 ? 11 : bp == 3 ? 7 : 15;
-                    const bool sym = grouped || bp == 3 || bp == 5;
-                    const int v = sym ? quant_sym(c, e, levels) : quant_asym(c, e, w ? w : 1);
-                    // quantised values live in 16 bits (qmant[] is unsigned short, :1347); only out-of-contract ones are wider than their field
-                    if (!grouped) put_bits(fr, P.frw, off, w, (uint32_t)v & 0xffffu);
-
-                    // a step opens at most 22 / 22 / 32 groups and one older group per kind can be incomplete
-                    uint32_t *slot = kind == 2 ? &L.gtab[64 + (grp & 63)] : &L.gtab[(kind == 1 ? 32 : 0) + (grp & 31)];
-                    const int wgt = mem == per - 1 ? 1 : mem == 0 ? (kind == 2 ? 11 : levels * levels) : levels;
+                    if (P.tap_bap)
+                        *reinterpret_cast<uint32_t *>(P.tap_bap + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) =
+                            ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                    const uint32_t gin = wave_incl_scan_u32(cnt_lane);
+                    uint32_t run = gin - cnt_lane;                          // ranks inside the pass of the lane's next bin, per kind
+                    uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
+                    uint32_t bits_lane = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
+                        const uint32_t r = ((run >> sh) & 1023u) + ((basem >> (2 * kind)) & 3u);    // rank counted from the open code's first member
+                        run += 1u << sh;
+                        const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
+                        const uint32_t gl = kind < 2 ? by3 : by2;                                  // r / 3 or r / 2 (both computed: a select, not a branch)
+                        const uint32_t per = 3u - (kind >> 1);
+                        const uint32_t idx = 4 * kind + (r - gl * per);                            // (kind, member)
+                        const uint32_t opens = (0x0111u >> idx) & 1u, last = (0x0244u >> idx) & 1u, member = (0x0266u >> idx) & 1u;
+                        const uint32_t grp = ((baseg >> (8 * kind)) & 255u) + gl;
+                        const uint32_t ring = 128u * kind + (grp & (127u | ((kind & 2u) << 6)));
+                        slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
+                        const uint32_t gbits = (pw[j] >> 7) & 7u;
+                        const uint32_t keep = opens;
+                        nb[j] = w + gbits * keep;
+                        bits_lane += nb[j];
+                        fl[j] = opens | (last << 1) | (member << 2) | (gbits << 4) | (gl << 8);
+                        // quantise (:1150-1190)
+                        const int levels = (int)((pw[j] >> 10) & 15u);
+                        const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
+                        const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
+                        const int q = ((pw[j] >> 14) & 1u) ? vs : va;
+                        const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
+                        vq[j] = (uint32_t)q & 0xffffu;
+                        vw[j] = (uint32_t)(q * wgt) << 16;
+                    }
+                    if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t kind = (pw[j] >> 5) & 3u;
+                            const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                            const uint32_t key = (kind << 16) | full;
+                            bool dropped = false;
+                            for (int q = 0; q < dropped_known; q++) dropped |= L.coll[q] == key;
+                            if (dropped && (fl[j] & 1u)) { bits_lane -= (fl[j] >> 4) & 7u; nb[j] -= (fl[j] >> 4) & 7u; }
+                        }
+                    }
+                    const uint32_t bin_ = wave_incl_scan_u32(bits_lane);
+                    uint32_t off = pos + bin_ - bits_lane;
+                    uint32_t offs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { offs[j] = off; off += nb[j]; }
+                    // plain mantissas: quantised values live in 16 bits (qmant[] is unsigned short, :1347); only out-of-contract
+                    // ones are wider than their field
+#pragma unroll
+                    for (int j = 0; j < 4; j++) put_bits_always(fr, P.frw, sink, offs[j], (int)(pw[j] & 31u), vq[j]);
                     // slot = bit offset | 16-bit code << 16: the code accumulates modulo 2^16 like *qmant_ptr += ...
-                    if (opens) *slot = off | ((uint32_t)(v * wgt) << 16);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) L.gtab[(fl[j] & 1u) ? slot[j] : 512u + 2u * (uint32_t)lane] = offs[j] | vw[j];
                     WAVE_SYNC();
-                    if (grouped && !opens) atomicAdd(slot, (uint32_t)(v * wgt) << 16);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) atomicAdd(&L.gtab[(fl[j] & 4u) ? slot[j] : 512u + 2u * (uint32_t)lane], vw[j]);
                     WAVE_SYNC();
-                    if (grouped && mem == per - 1) {
-                        const uint32_t x = *slot;
-                        if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
-                        else if (attempt == 0) { const int q = atomicAdd(&L.ncoll, 1); if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
+                    uint32_t hit = 0;
+                    uint32_t xs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        xs[j] = L.gtab[(fl[j] & 2u) ? slot[j] : 512u + 2u * (uint32_t)lane];
+                        const uint32_t coll = ((fl[j] >> 1) & 1u) * ((xs[j] >> 16) == marker ? 1u : 0u);
+                        hit |= coll;
+                        put_bits_always(fr, P.frw, sink, xs[j] & 0xffffu, (int)(((fl[j] >> 4) & 7u) * ((fl[j] >> 1) & 1u) * (1u - coll)), xs[j] >> 16);
                     }
-
-                    b3 += (int)(gtot & 255u); b5 += (int)((gtot >> 8) & 255u); b11 += (int)(gtot >> 16);
-                    pos += wave_last(bincl);
+                    if (attempt == 0 && __ballot(hit != 0)) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
+                                const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
+                                const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                                const int q = atomicAdd(&L.ncoll, 1);
+                                if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | full;
+                            }
+                    }
+                    WAVE_SYNC();
+                    {
+                        const uint32_t gtot = wave_last(gin);
+                        const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
+                        b3 += t3; b5 += t5; b11 += t11;
+                        baseg = (uint32_t)((b3 / 3) & 255) | ((uint32_t)((b5 / 3) & 255) << 8) | ((uint32_t)((b11 >> 1) & 255) << 16);
+                        basem = (uint32_t)(b3 % 3) | ((uint32_t)(b5 % 3) << 2) | ((uint32_t)(b11 & 1) << 4);
+                    }
+                    pos += wave_last(bin_);
                 }
                 // a trailing group that never got its last member is written as it stands
                 WAVE_SYNC();
@@ -1233,9 +1349,9 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
                         if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
                         else if (attempt == 0) { const int q = L.ncoll++; if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
                     };
-                    if (b3 % 3) tail(0, b3 / 3, L.gtab[(b3 / 3) & 31], 5);
-                    if (b5 % 3) tail(1, b5 / 3, L.gtab[32 + ((b5 / 3) & 31)], 7);
-                    if (b11 & 1) tail(2, b11 >> 1, L.gtab[64 + ((b11 >> 1) & 63)], 7);
+                    if (b3 % 3) tail(0, b3 / 3, L.gtab[(b3 / 3) & 127], 5);
+                    if (b5 % 3) tail(1, b5 / 3, L.gtab[128 + ((b5 / 3) & 127)], 7);
+                    if (b11 & 1) tail(2, b11 >> 1, L.gtab[256 + ((b11 >> 1) & 255)], 7);
                 }
                 WAVE_SYNC();
                 const int ncoll = (int)__builtin_amdgcn_readfirstlane(L.ncoll);
@@ -1252,6 +1368,7 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
               }
             }
             WAVE_SYNC();
+            PK_LAP(2);
         }
 
         // ---- frame end (:1599-1638): bytes past 2*fs are dropped, CRCs stored over whatever is there ----
@@ -1277,9 +1394,20 @@ __global__ __launch_bounds__(64, 5) void enc_pack_kernel(const PackParams P)
             else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
         }
         WAVE_SYNC();
+        PK_LAP(3);
     }
     if ((PART == 0 || PART == 1) && lane == 0) P.csnr_state[sslot] = csnr_prev;
+    PK_END();
 }
+
+#ifdef PACK_STAMPS
+extern "C" __attribute__((visibility("default"))) int ac3mi_debug_pack_cycles(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pack_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pack_cycles), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 
