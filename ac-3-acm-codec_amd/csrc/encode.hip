@@ -711,7 +711,9 @@ __device__ __forceinline__ void put_bits_always(uint32_t *fr, int frw, uint32_t 
     atomicOr(dst + 1, (uint32_t)x);
 }
 
-// L.bitlut[address] = plain mantissa width | (bap==1) << 10 | (bap==2) << 16 | (bap==4) << 22 | bap << 28.
+// L.bitlut[address] = plain mantissa width | (bap==1) << 9 | (bap==2) << 14 | (bap==4) << 19: 24 bits, so that a lane's sums
+// over a frame's rows (width <= 6 x 4 x 16 = 384, counts <= 24) stay clear of each other and a sum can be added to a block's
+// account with one v_mad_u32_u24.
 // lut_index returns the address with d4 = 4 * (80 - 4 exp) (hugely negative for a padding item: address 0,
 // bap 0, no bits).
 
@@ -722,6 +724,21 @@ __device__ __forceinline__ int lut_index(int d4, int mask_minus_floor, int snrof
     int a4 = d4 - q4;
     a4 = a4 < 0 ? 0 : a4 > 252 ? 252 : a4;
     return a4 >> 2;
+}
+
+// two offsets at once in packed 16-bit arithmetic (every quantity of lut_index fits 16 bits: masks and offsets are below
+// 2^13 in magnitude, d4 of a padding item is -16384 here): returns the two addresses * 4 = byte offsets into bitlut
+typedef short pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 lut_index2(int d4, int mask_minus_floor, pk2 snroffsets)
+{
+    const pk2 mm = {(short)mask_minus_floor, (short)mask_minus_floor}, dd = {(short)d4, (short)d4};
+    pk2 q = (mm - snroffsets) >> 3;
+    q &= (pk2){(short)~3, (short)~3};
+    q = __builtin_elementwise_max(q, (pk2){0, 0});
+    pk2 a = dd - q;
+    a = __builtin_elementwise_max(a, (pk2){0, 0});
+    a = __builtin_elementwise_min(a, (pk2){252, 252});
+    return a;
 }
 
 // plain (ungrouped) mantissa width of a bap code; 0 for the grouped codes 1, 2, 4 and for 0
@@ -872,7 +889,7 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
     }
     {
         const int bp = P.tab->baptab[lane];
-        L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 10) | ((bp == 2) << 16) | ((bp == 4) << 22) | ((uint32_t)bp << 28);
+        L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 9) | ((bp == 2) << 14) | ((bp == 4) << 19);
         L.packlut[lane] = pack_word(bp);
     }
 
@@ -999,6 +1016,7 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 uint64_t t1 = todo & (todo - 1), t2 = t1 & (t1 - 1);
                 int r1 = row_of(t1, r), r2 = row_of(t2, r1);
                 uint32_t ev = fetch(r), ev1 = fetch(r1), ev2 = fetch(r2);
+                const pk2 so01 = {(short)so[0], (short)so[1]};
 #pragma unroll 1
                 while (todo) {
                     todo &= todo - 1;
@@ -1014,13 +1032,19 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int e = (ev >> (8 * j)) & 0xff, m = Mr[(bandoff >> (8 * j)) & 0xff];
-                        const int d4 = 4 * lane + j < n ? 320 - 16 * e : -(1 << 20);
-#pragma unroll
-                        for (int k = 0; k < 3; k++) sum[k] += L.bitlut[lut_index(d4, m, so[k])];
+                        const int d4 = 4 * lane + j < n ? 320 - 16 * e : -16384;
+                        const pk2 a01 = lut_index2(d4, m, so01);
+                        sum[0] += L.bitlut[(uint16_t)a01.x >> 2];
+                        sum[1] += L.bitlut[(uint16_t)a01.y >> 2];
+                        sum[2] += L.bitlut[lut_index(d4, m, so[2])];
                     }
 #pragma unroll
-                    for (int B = 0; B < 6; B++)
-                        if (B >= b0 && B < b1) { acc[B][0] += sum[0]; acc[B][1] += sum[1]; acc[B][2] += sum[2]; }
+                    for (int B = 0; B < 6; B++) {
+                        const uint32_t in_run = (B >= b0 && B < b1) ? 1u : 0u;       // wave-uniform
+#pragma unroll
+                        for (int k = 0; k < 3; k++)         // (written out: the compiler turns a multiply by 0/1 back into select + add)
+                            asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[B][k]) : "v"(sum[k]), "s"(in_run));
+                    }
                     r = r1; r1 = r2; r2 = r3;
                     ev = ev1; ev1 = ev2; ev2 = ev3;
                     t2 = t3;
@@ -1031,8 +1055,8 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             for (int B = 0; B < 6; B++) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const uint32_t sa = wave_sum_u32((acc[B][c] & 0x3ffu) | (((acc[B][c] >> 10) & 63u) << 16));
-                    const uint32_t sb = wave_sum_u32(((acc[B][c] >> 16) & 63u) | (((acc[B][c] >> 22) & 63u) << 16));
+                    const uint32_t sa = wave_sum_u32((acc[B][c] & 0x1ffu) | (((acc[B][c] >> 9) & 31u) << 16));
+                    const uint32_t sb = wave_sum_u32(((acc[B][c] >> 14) & 31u) | (((acc[B][c] >> 19) & 31u) << 16));
                     const int bits = sa & 0xffff, n1 = sa >> 16, n2 = sb & 0xffff, n4 = sb >> 16;
                     total[c] += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
                 }

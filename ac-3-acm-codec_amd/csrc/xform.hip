@@ -323,6 +323,11 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     // 4 workgroups per CU (LDS: 40 KB each); measured on MI355X: 3 vs 4 waves/SIMD, packed vs scalar f32 and
     // 8- vs 16-byte accesses all land within 1 % - the kernel runs at the rate of a plain copy with the same
     // addressing (profiles/r01_xform_probes.md)
+    // Workgroups per CU are capped through the LDS request: the float identity kernel fits four per CU (40 KB, 116 VGPRs) but
+    // runs 3.4 % faster with three - fewer chains in flight keep the DRAM pages of the coefficient and PCM streams open longer
+    // (measured on MI355X, 65 536 frames: 4 per CU 0.979 / 0.950 ms, 3 per CU 0.947 / 0.916 ms, 2 per CU 1.082 ms; the bare copy
+    // with this addressing shows the same trend, profiles/hbm_calibrate).  AC3MI_XFORM_LDS_PAD overrides (occupancy sweeps).
+    static const int lds_pad = getenv("AC3MI_XFORM_LDS_PAD") ? atoi(getenv("AC3MI_XFORM_LDS_PAD")) : 14 * 1024;
     P.pcm16 = L.pcm16;
     if (L.pcm16) {
         int map[6];
@@ -335,7 +340,7 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
         return hipGetLastError();
     }
     if (identity)
-        hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), lds_pad, stream, P);
     else        // 167 VGPRs with the planes of an output accumulated one after the other (187 with their loads unrolled): 3 workgroups per CU
         hipLaunchKernelGGL((xform_kernel<true, 3>), dim3(grid), dim3(256), 0, stream, P);
     return hipGetLastError();
