@@ -548,7 +548,15 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
     __shared__ ExpLDS XL;
 
     const int lane = threadIdx.x;
-    const int unit = blockIdx.x;                    // (s*F + f)*nch + ch
+    // The nch wavefronts of a frame de-interleave the same PCM lines, one channel each.  Workgroups are dealt round-robin over the
+    // 8 XCDs (private L2s), so with unit = blockIdx the channels of a frame sat on different XCDs and each fetched the frame's
+    // samples for itself (PMC: 114 KB fetched per frame against 18 KB of PCM).  The bijective remap of cdna_hip_programming.md
+    // (T1) makes consecutive units share an XCD: blocks with equal blockIdx % 8 take one contiguous range of units.
+    int unit;                                       // (s*F + f)*nch + ch
+    {
+        const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        unit = (int)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i);
+    }
     const int ch = unit % P.nch;
     const int sf = unit / P.nch;
     const int f = sf % P.frames;
