@@ -106,6 +106,7 @@ def load_library():
     lib.ac3mi_encode_batch.argtypes = [c_void_p, ctypes.POINTER(EncodeDescC), c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, ctypes.POINTER(EncodeTapsC)]
     lib.ac3mi_set_decode_mode.argtypes = [c_void_p, ctypes.c_int]
+    lib.ac3mi_set_mix_state.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.ac3mi_probe_valu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_probe_salu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_set_tile_frames.argtypes = [c_void_p, ctypes.c_longlong]

@@ -56,6 +56,10 @@ struct MixPlan {
     int n_in, n_out, nfchans, in_lfe;
     // mix[o][c]: weight (-1, 0, +1) of input plane c in output plane o
     int8_t mix[6][6];
+    // Surround planes that liba52 mixes at level slev into MONO / STEREO / 3F (bit c = input plane c), 0 elsewhere: when a
+    // frame's slev is 0 liba52 neither transforms nor mixes them (L52/parse.c:900-913, downmix.c:494-583), which is not a
+    // linear mix at level 0 as far as their overlap tails go - see XformLaunch::mix_pending.
+    uint8_t surr_mask;
 };
 
 struct XformLaunch {
@@ -73,6 +77,13 @@ struct XformLaunch {
     // reference's MapTab converters make of a52_samples() at bias 384 (src/AC3ASM.asm; s16_channel_map).  pcm is unused then.
     int16_t *pcm16 = nullptr;
     int s16_flags = 0;      // liba52 output flags of the planes (selects the channel order)
+    // liba52's overlap bookkeeping around frames whose surround mix level is 0 (ac3mi_set_mix_state): per frame "slev is 0"
+    // from the decode front end, per output chain the surround planes' share of the overlap tail that is held back
+    // ([streams or slots][n_out][128], laid out like `delay`) and its flags ([streams or slots][6]: bit 0 liba52's
+    // `downmixed`, bit 1 share pending).  All three null: a plain linear mix.
+    const uint8_t *zs = nullptr;
+    float *mix_pending = nullptr;
+    int32_t *mix_flags = nullptr;
 };
 
 // a52_downmix()/a52_downmix_init() semantics as a plane-mixing matrix; returns <0 if
@@ -92,6 +103,7 @@ struct DecodeLaunch {
     uint16_t *lfsr;         // [S]
     uint8_t *tap_exp;
     int8_t *tap_bap;
+    uint8_t *zs = nullptr;              // optional [S][F]: 1 = the frame's surround channels are mixed at level 0 (see XformLaunch)
     float *dyn_out = nullptr;           // [S][F][6][2] range factors of the stream's dynamic-range words (NaN: none)
     const float *dyn_in = nullptr;      // [S][F][6][2] replacements (NaN: keep)
     const int32_t *slot;
@@ -159,6 +171,9 @@ struct ac3mi_ctx {
     size_t ws_tc_bytes;
     // optional state-slot indirection for the next batch calls (ac3mi_set_state_slots)
     const int32_t *slots;
+    // optional liba52-exact overlap state around frames with surround level 0 (ac3mi_set_mix_state)
+    float *mix_pending;
+    int32_t *mix_flags;
     bool no_overlap;        // AC3MI_NO_OVERLAP in the environment: no chunk pipelines (clean per-kernel profiles)
     long long tile_frames;  // workspace bound: batches above this many frames go through in tiles of whole streams (0 = never)
     int decode_mode;        // 0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame

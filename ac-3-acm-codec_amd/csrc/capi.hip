@@ -313,6 +313,11 @@ int build_mix_plan(int acmod, int lfeon, int output, MixPlan *plan)
     for (int o = 0; o < nfo; o++)
         for (int c = 0; c < plan->nfchans; c++) plan->mix[o + out_lfe][c + plan->in_lfe] = m[o][c];
     if (out_lfe) plan->mix[0][0] = 1;
+    // the outputs whose time-domain mixers test slev == 0 (downmix.c:494-583), from the acmods with surround channels
+    if ((A & 4) && (out == AC3MI_MONO || out == AC3MI_STEREO || out == AC3MI_3F)) {
+        const int nsurr = A >= 6 ? 2 : 1;
+        for (int c = plan->nfchans - nsurr; c < plan->nfchans; c++) plan->surr_mask |= (uint8_t)(1u << (c + plan->in_lfe));
+    }
     return AC3MI_OK;
 }
 
@@ -455,6 +460,8 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->ws_draws_bytes = 0;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
+    ctx->mix_pending = nullptr;
+    ctx->mix_flags = nullptr;
     ctx->ws_coef_bytes = ctx->ws_blksw_bytes = 0;
     if (ctx_init(ctx) != AC3MI_OK) {
         g_err = ctx->err;
@@ -605,6 +612,14 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots)
 {
     if (!ctx) return AC3MI_ERR_ARG;
     ctx->slots = d_slots;
+    return AC3MI_OK;
+}
+
+int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags)
+{
+    if (!ctx || ((d_pending == nullptr) != (d_flags == nullptr))) return AC3MI_ERR_ARG;
+    ctx->mix_pending = d_pending;
+    ctx->mix_flags = d_flags;
     return AC3MI_OK;
 }
 
@@ -794,29 +809,40 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     if (const int g = (taps || fused) ? 0 : tile_streams(ctx, n_streams, frames_per_stream)) {
         // bounded workspace: whole streams at a time (streams are independent; state arrays move with them)
         const int32_t *slots0 = ctx->slots;
+        float *const mp0 = ctx->mix_pending;
+        int32_t *const mf0 = ctx->mix_flags;
         int rc = AC3MI_OK;
         for (int s0 = 0; s0 < n_streams && rc == AC3MI_OK; s0 += g) {
             const int ns = n_streams - s0 < g ? n_streams - s0 : g;
             const size_t f0 = (size_t)s0 * frames_per_stream;
             if (slots0) ctx->slots = slots0 + s0;
+            else if (mp0) { ctx->mix_pending = mp0 + (size_t)s0 * n_out * 128; ctx->mix_flags = mf0 + (size_t)s0 * 6; }
             rc = decode_impl(ctx, desc, d_frames + f0 * frame_stride, frame_stride, ns, frames_per_stream,
                              slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0,
                              d_pcm ? d_pcm + f0 * 6 * n_out * 256 : nullptr, d_pcm16 ? d_pcm16 + f0 * 6 * n_out * 256 : nullptr,
                              d_status + f0, nullptr);
         }
         ctx->slots = slots0;
+        ctx->mix_pending = mp0;
+        ctx->mix_flags = mf0;
         return rc;
     }
     const size_t nfr = (size_t)n_streams * frames_per_stream;
     float *coef = taps && taps->d_coef ? taps->d_coef : nullptr;
     uint8_t *blksw = taps && taps->d_blksw ? taps->d_blksw : nullptr;
+    // liba52's overlap bookkeeping around frames with surround level 0: the front end tells the transform which they are
+    const bool mixstate = ctx->mix_pending && X.plan.surr_mask && !identity;
+    uint8_t *zs = nullptr;
     if (!fused) {
-        int r = ensure_ws(ctx, coef ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float),
-                          blksw ? 0 : nfr * 6 * X.plan.nfchans + 4);
+        const size_t zs_off = blksw ? 0 : nfr * 6 * X.plan.nfchans + 4;
+        int r = ensure_ws(ctx, coef ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0));
         if (r != AC3MI_OK) return r;
+        if (mixstate) zs = ctx->ws_blksw + zs_off;
         if (!coef) coef = ctx->ws_coef;
         if (!blksw) blksw = ctx->ws_blksw;
     }
+    X.mix_pending = mixstate ? ctx->mix_pending : nullptr;
+    X.mix_flags = mixstate ? ctx->mix_flags : nullptr;
 
     const bool fp = !wgk && use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
@@ -837,6 +863,7 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.level = desc->level;
         D.coef = coef;
         D.blksw = blksw;
+        D.zs = zs;
         D.status = d_status;
         D.lfsr = d_lfsr;
         D.slot = ctx->slots;
@@ -849,6 +876,7 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.frame_lfsr = nullptr;
         X.coef = coef;
         X.blksw = blksw;
+        X.zs = zs;
         X.delay = d_delay;
         X.slot = ctx->slots;
         X.delay_stride = 6 * 128;
@@ -888,6 +916,7 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.level = desc->level;
         D.coef = coef + f0 * 6 * X.plan.n_in * 256;
         D.blksw = blksw + f0 * 6 * X.plan.nfchans;
+        D.zs = zs ? zs + f0 : nullptr;
         D.status = d_status + f0;
         D.lfsr = ctx->slots ? d_lfsr : d_lfsr + s0;
         D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
@@ -908,6 +937,11 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         }
         X.coef = D.coef;
         X.blksw = D.blksw;
+        X.zs = D.zs;
+        if (mixstate && !ctx->slots) {
+            X.mix_pending = ctx->mix_pending + (size_t)s0 * X.plan.n_out * 128;
+            X.mix_flags = ctx->mix_flags + (size_t)s0 * 6;
+        }
         X.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * X.plan.n_out * 128;
         X.slot = D.slot;
         X.delay_stride = 6 * 128;
@@ -1124,22 +1158,30 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (const int g = tile_streams(ctx, n_streams, frames_per_stream)) {
         const int32_t *slots0 = ctx->slots;
+        float *const mp0 = ctx->mix_pending;
+        int32_t *const mf0 = ctx->mix_flags;
         int rc = AC3MI_OK;
         for (int s0 = 0; s0 < n_streams && rc == AC3MI_OK; s0 += g) {
             const int ns = n_streams - s0 < g ? n_streams - s0 : g;
             const size_t f0 = (size_t)s0 * frames_per_stream;
             if (slots0) ctx->slots = slots0 + s0;
+            else if (mp0) { ctx->mix_pending = mp0 + (size_t)s0 * n_out * 128; ctx->mix_flags = mf0 + (size_t)s0 * 6; }
             rc = ac3mi_transcode_batch(ctx, dec, enc, d_frames_in + f0 * in_stride, in_stride, ns, frames_per_stream,
                                        slots0 ? d_delay : d_delay + (size_t)s0 * n_out * 128, slots0 ? d_lfsr : d_lfsr + s0, chmap,
                                        slots0 ? d_last : d_last + (size_t)s0 * E.cfg.nch * 256, slots0 ? d_csnroffst : d_csnroffst + s0,
                                        d_frames_out + f0 * out_stride, out_stride, d_status + f0);
         }
         ctx->slots = slots0;
+        ctx->mix_pending = mp0;
+        ctx->mix_flags = mf0;
         return rc;
     }
     const size_t F = (size_t)frames_per_stream, nfr = (size_t)n_streams * F;
     // workspaces: decoder planes, float PCM + s16 PCM, encoder arrays
-    { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), nfr * 6 * X.plan.nfchans + 4); if (r != AC3MI_OK) return r; }
+    const bool mixstate = ctx->mix_pending && X.plan.surr_mask;       // as in decode_impl
+    const size_t zs_off = nfr * 6 * X.plan.nfchans + 4;
+    { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0)); if (r != AC3MI_OK) return r; }
+    uint8_t *const zs = mixstate ? ctx->ws_blksw + zs_off : nullptr;
     const size_t s16_bytes = nfr * 1536 * n_out * 2;       // the transform writes s16 itself: no float PCM in between
     if (s16_bytes + 512 > ctx->ws_tc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1189,6 +1231,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         D.level = dd.level;
         D.coef = ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
         D.blksw = ctx->ws_blksw + f0 * 6 * X.plan.nfchans;
+        D.zs = zs ? zs + f0 : nullptr;
         D.status = d_status + f0;
         D.lfsr = ctx->slots ? d_lfsr : d_lfsr + s0;
         D.slot = ctx->slots ? ctx->slots + s0 : nullptr;
@@ -1220,6 +1263,11 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         XformLaunch Y = X;
         Y.coef = ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
         Y.blksw = ctx->ws_blksw + f0 * 6 * X.plan.nfchans;
+        Y.zs = zs ? zs + f0 : nullptr;
+        if (mixstate) {
+            Y.mix_pending = ctx->slots ? ctx->mix_pending : ctx->mix_pending + (size_t)s0 * n_out * 128;
+            Y.mix_flags = ctx->slots ? ctx->mix_flags : ctx->mix_flags + (size_t)s0 * 6;
+        }
         Y.delay = ctx->slots ? d_delay : d_delay + (size_t)s0 * n_out * 128;
         Y.slot = ctx->slots ? ctx->slots + s0 : nullptr;
         Y.delay_stride = 6 * 128;

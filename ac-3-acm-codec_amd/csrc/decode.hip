@@ -555,6 +555,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
             __builtin_amdgcn_wave_barrier();
         }
         if (MODE != 1 && lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
+        if (MODE != 1 && lane == 0 && P.zs) P.zs[fidx] = (uint8_t)((status & 0x100u) ? 0 : surround_level_is_zero(st.acmod, st.output, st.slev));
         if (MODE == 1 && lane == 0) P.frame_draws[fidx] = frame_draws;
     }
     if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
@@ -587,6 +588,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     P.frames = L.frames;
     P.coef = L.coef;
     P.blksw = L.blksw;
+    P.zs = L.zs;
     P.status = L.status;
     P.lfsr_state = L.lfsr;
     P.slot = L.slot;

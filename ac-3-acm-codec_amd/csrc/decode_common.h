@@ -103,6 +103,14 @@ __device__ __forceinline__ float sf_of(int e) { return __int_as_float((127 - 15 
 
 __device__ __forceinline__ int wave_incl_scan(int v, int) { return (int)wave_incl_scan_u32((uint32_t)v); }
 
+// liba52 drops the surround channels of such a frame from transform and mix instead of mixing them at level 0
+// (L52/downmix.c:494-583: the slev == 0 cases of MONO, STEREO and 3F outputs)
+__device__ __forceinline__ int surround_level_is_zero(int acmod, int output, float slev)
+{
+    const int out = output & 15;
+    return ((acmod & 4) && slev == 0.f && (out == 1 || out == 2 || out == 3)) ? 1 : 0;
+}
+
 // stream-persistent decoder fields (wave-uniform)
 struct St {
     int fscod, halfrate, acmod, lfeon, nf;
@@ -123,6 +131,7 @@ struct DecodeParams {
     const uint8_t *frames;
     float *coef;
     uint8_t *blksw;
+    uint8_t *zs;            // optional [S][F]: the frame mixes its surround channels at level 0 (liba52: coeff[i] == 0)
     uint32_t *status;
     uint16_t *lfsr_state;
     uint8_t *tap_exp;       // optional [S][F][6][7][256]

@@ -1102,6 +1102,7 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
             if (wave == W_PARSE && lane == 0) {
                 const uint32_t st = S.status;
                 P.status[fidx] = st | ((st & 0x100u) ? 0x3fu : 0u) | (S.reuse0 ? 0x200u : 0u);
+                if (P.zs) P.zs[fidx] = (uint8_t)((st & 0x100u) ? 0 : surround_level_is_zero(S.acmod, S.output, S.slev));
             }
             STAMP(53);
             wg_barrier();                                            // the frame buffer and the planes are free
@@ -1123,6 +1124,7 @@ hipError_t launch_decode_wg(const DeviceTables &tab, const DecodeLaunch &D, cons
     P.frames = D.frames;
     P.coef = D.coef;
     P.blksw = D.blksw;
+    P.zs = D.zs;
     P.status = D.status;
     P.lfsr_state = D.lfsr;
     P.slot = D.slot;

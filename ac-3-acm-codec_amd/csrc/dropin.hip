@@ -109,12 +109,15 @@ struct a52_state_s {
     void *dyn_data;
     // device side
     uint8_t *d_frame;
-    float *d_delay, *d_pcm;
+    float *d_delay, *d_pcm;     // d_delay: overlap tails [6][128], then the mix state of ac3mi_set_mix_state: pending [6][128], flags [6]
     uint16_t *d_lfsr;
     uint32_t *d_status;
     float *d_dyn;               // 12 range factors out + 12 in (callback frames only)
     float *d_scratch;           // overlap tails + dither state of the look-ahead pass
 };
+
+// layout of a52_state_s::d_delay (and of d_scratch, which has the dither state behind it)
+constexpr size_t ST_PENDING = 6 * 128, ST_FLAGS = 2 * 6 * 128, ST_FLOATS = 2 * 6 * 128 + 8;
 
 extern "C" {
 
@@ -142,18 +145,18 @@ a52_state_t *a52_init(uint32_t mm_accel)
     if (!st) return nullptr;
     st->samples = (float *)calloc(256 * 12, sizeof(float));
     st->d_frame = (uint8_t *)ac3mi_dev_alloc(ctx, 3840 + 8);
-    st->d_delay = (float *)ac3mi_dev_alloc(ctx, 6 * 128 * sizeof(float));
+    st->d_delay = (float *)ac3mi_dev_alloc(ctx, ST_FLOATS * sizeof(float));
     st->d_pcm = (float *)ac3mi_dev_alloc(ctx, sizeof st->pcm);
     st->d_lfsr = (uint16_t *)ac3mi_dev_alloc(ctx, 4);
     st->d_status = (uint32_t *)ac3mi_dev_alloc(ctx, 4);
     st->d_dyn = (float *)ac3mi_dev_alloc(ctx, 24 * sizeof(float));
-    st->d_scratch = (float *)ac3mi_dev_alloc(ctx, 6 * 128 * sizeof(float) + 16);
+    st->d_scratch = (float *)ac3mi_dev_alloc(ctx, ST_FLOATS * sizeof(float) + 16);
     if (!st->samples || !st->d_frame || !st->d_delay || !st->d_pcm || !st->d_lfsr || !st->d_status || !st->d_dyn || !st->d_scratch) {
         a52_free(st);
         return nullptr;
     }
     const uint16_t one = 1;                              // lfsr_state = 1 (parse.c:75)
-    ac3mi_memset(ctx, st->d_delay, 0, 6 * 128 * sizeof(float));
+    ac3mi_memset(ctx, st->d_delay, 0, ST_FLOATS * sizeof(float));
     ac3mi_memcpy_h2d(ctx, st->d_lfsr, &one, 2);
     st->dynrng = 1;
     return st;
@@ -243,23 +246,29 @@ static int dropin_decode(a52_state_t *st)
         // a52_block, parse.c:593-594; here all calls of a frame happen at its first a52_block), and the frame is decoded
         // with the mapped values in their place.
         float words[12], mapped[12];
-        uint16_t *d_lfsr2 = (uint16_t *)(st->d_scratch + 6 * 128);
-        if (hipMemcpyAsync(st->d_scratch, st->d_delay, 6 * 128 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+        uint16_t *d_lfsr2 = (uint16_t *)(st->d_scratch + ST_FLOATS);
+        if (hipMemcpyAsync(st->d_scratch, st->d_delay, ST_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(d_lfsr2, st->d_lfsr, 2, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             return -1;
         for (int i = 0; i < 12; i++) words[i] = __builtin_nanf("");
         if (ac3mi_memcpy_h2d(ctx, st->d_dyn, words, sizeof words) != AC3MI_OK) return -1;
         taps.d_dynrng_out = st->d_dyn;
-        if (ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_scratch, d_lfsr2, st->d_pcm, st->d_status, &taps) != AC3MI_OK) return -1;
+        ac3mi_set_mix_state(ctx, st->d_scratch + ST_PENDING, (int32_t *)(st->d_scratch + ST_FLAGS));
+        const int rc0 = ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_scratch, d_lfsr2, st->d_pcm, st->d_status, &taps);
+        ac3mi_set_mix_state(ctx, nullptr, nullptr);
+        if (rc0 != AC3MI_OK) return -1;
         if (ac3mi_memcpy_d2h(ctx, words, st->d_dyn, sizeof words) != AC3MI_OK) return -1;
         for (int i = 0; i < 12; i++) mapped[i] = words[i] == words[i] ? st->dyn_call(words[i], st->dyn_data) : words[i];
         if (ac3mi_memcpy_h2d(ctx, st->d_dyn + 12, mapped, sizeof mapped) != AC3MI_OK) return -1;
         taps.d_dynrng_out = nullptr;
         taps.d_dynrng_in = st->d_dyn + 12;
     }
-    if (ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_delay, st->d_lfsr, st->d_pcm, st->d_status,
-                           st->dyn_call ? &taps : nullptr) != AC3MI_OK)
-        return -1;
+    // liba52's own overlap bookkeeping around frames with surround level 0 (include/ac3mi.h, ac3mi_set_mix_state)
+    ac3mi_set_mix_state(ctx, st->d_delay + ST_PENDING, (int32_t *)(st->d_delay + ST_FLAGS));
+    const int rc1 = ac3mi_decode_batch(ctx, &d, st->d_frame, stride, 1, 1, st->d_delay, st->d_lfsr, st->d_pcm, st->d_status,
+                                       st->dyn_call ? &taps : nullptr);
+    ac3mi_set_mix_state(ctx, nullptr, nullptr);
+    if (rc1 != AC3MI_OK) return -1;
     if (ac3mi_memcpy_d2h(ctx, st->pcm, st->d_pcm, (size_t)6 * n_out * 256 * sizeof(float)) != AC3MI_OK) return -1;
     if (ac3mi_memcpy_d2h(ctx, &st->status, st->d_status, 4) != AC3MI_OK) return -1;
     st->decoded = 1;

@@ -198,6 +198,8 @@ struct ac3mi_pool {
     std::vector<char> dirty;        // slot state differs from a fresh a52_init / AC3_encode_init
     // per-slot carry-over state (device)
     float *d_delay;         // [cap][6][128]
+    float *d_mixp;          // [cap][6][128]  ac3mi_set_mix_state: liba52's overlap bookkeeping around surround level 0
+    int32_t *d_mixf;        // [cap][6]
     uint16_t *d_lfsr;       // [cap]
     int16_t *d_last;        // [cap][6][256]
     int32_t *d_csnr;        // [cap]
@@ -486,8 +488,10 @@ int decode_group(ac3mi_pool *p, const std::vector<ac3mi_stream *> &group, int ba
             return fail(p, AC3MI_MMSYSERR_NOMEM, "copy");
         }
         ac3mi_set_state_slots(ctx, d_slots + lo);
+        ac3mi_set_mix_state(ctx, p->d_mixp, p->d_mixf);
         const int rc = ac3mi_decode_s16_batch(ctx, &d, d_frames + (size_t)lo * fstride, fstride, kc, 1, p->d_delay, p->d_lfsr,
                                               (int16_t *)((uint8_t *)d_s16 + (size_t)lo * 6 * blk), d_status + lo);
+        ac3mi_set_mix_state(ctx, NULL, NULL);
         ac3mi_set_state_slots(ctx, NULL);
         if (rc != AC3MI_OK) { (void)hipDeviceSynchronize(); return fail(p, AC3MI_MMSYSERR_NOMEM, "decode batch"); }
         if (hipEventRecord(p->ev_kernel[c], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, p->ev_kernel[c], 0) != hipSuccess ||
@@ -581,6 +585,8 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
     auto dev = [&](size_t bytes) -> void * { void *q = ac3mi_dev_alloc(ctx, bytes); ok = ok && q; return q; };
     auto pin = [&](size_t bytes) -> void * { void *q = nullptr; if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { q = nullptr; ok = false; } return q; };
     p->d_delay = (float *)dev(n * 6 * 128 * 4);
+    p->d_mixp = (float *)dev(n * 6 * 128 * 4);
+    p->d_mixf = (int32_t *)dev(n * 6 * 4);
     p->d_lfsr = (uint16_t *)dev(n * 2);
     p->d_last = (int16_t *)dev(n * 6 * 256 * 2);
     p->d_csnr = (int32_t *)dev(n * 4);
@@ -601,6 +607,7 @@ ac3mi_pool *ac3mi_pool_create(ac3mi_ctx *ctx, int capacity)
         std::vector<uint16_t> ones(n, 1);
         std::vector<int32_t> forty(n, 40);
         ok = ac3mi_memset(ctx, p->d_delay, 0, n * 6 * 128 * 4) == AC3MI_OK && ac3mi_memset(ctx, p->d_last, 0, n * 6 * 256 * 2) == AC3MI_OK &&
+             ac3mi_memset(ctx, p->d_mixp, 0, n * 6 * 128 * 4) == AC3MI_OK && ac3mi_memset(ctx, p->d_mixf, 0, n * 6 * 4) == AC3MI_OK &&
              ac3mi_memcpy_h2d(ctx, p->d_lfsr, ones.data(), n * 2) == AC3MI_OK &&
              ac3mi_memcpy_h2d(ctx, p->d_csnr, forty.data(), n * 4) == AC3MI_OK && ac3mi_sync(ctx) == AC3MI_OK;
     }
@@ -613,7 +620,7 @@ void ac3mi_pool_destroy(ac3mi_pool *p)
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)ac3mi_sync(p->ctx);
-    void *dv[] = {p->d_delay, p->d_lfsr, p->d_last, p->d_csnr, p->d_slots, p->d_frames, p->d_s16, p->d_status};
+    void *dv[] = {p->d_mixp, p->d_mixf, p->d_delay, p->d_lfsr, p->d_last, p->d_csnr, p->d_slots, p->d_frames, p->d_s16, p->d_status};
     for (void *q : dv) if (q) ac3mi_dev_free(p->ctx, q);
     void *hv[] = {p->h_slots, p->h_frames, p->h_s16, p->h_status};
     for (void *q : hv) if (q) (void)hipHostFree(q);
@@ -730,6 +737,8 @@ int ac3mi_stream_open(ac3mi_pool *pool, const ac3mi_wavefmt *src, const ac3mi_wa
         const uint16_t one = 1;
         const int32_t c40 = 40;
         ok = ok && ac3mi_memset(ctx, pool->d_delay + (size_t)st->slot * 6 * 128, 0, 6 * 128 * 4) == AC3MI_OK;
+        ok = ok && ac3mi_memset(ctx, pool->d_mixp + (size_t)st->slot * 6 * 128, 0, 6 * 128 * 4) == AC3MI_OK;
+        ok = ok && ac3mi_memset(ctx, pool->d_mixf + (size_t)st->slot * 6, 0, 6 * 4) == AC3MI_OK;
         ok = ok && ac3mi_memcpy_h2d(ctx, pool->d_lfsr + st->slot, &one, 2) == AC3MI_OK;
         ok = ok && ac3mi_memset(ctx, pool->d_last + (size_t)st->slot * 6 * 256, 0, 6 * 256 * 2) == AC3MI_OK;
         ok = ok && ac3mi_memcpy_h2d(ctx, pool->d_csnr + st->slot, &c40, 4) == AC3MI_OK;

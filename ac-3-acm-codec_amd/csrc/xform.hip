@@ -47,6 +47,12 @@ struct XformParams {
     int16_t *pcm16;
     int8_t wslot[6];
     int n_streams, gps;
+    // liba52's overlap bookkeeping around frames whose surround level is 0 (XformLaunch::mix_pending): null = linear mix
+    const uint8_t *zs;          // [S][frames] or null
+    float *mix_pending;         // per chain 128 floats, indexed like `delay`
+    int32_t *mix_flags;         // per stream slot 6 words (one per output chain): bit 0 `downmixed`, bit 1 share pending
+    uint32_t surr_mask;         // input planes that are surround channels mixed at slev
+    int downmixing;             // fewer full-bandwidth outputs than coded channels (parse.c:881-883)
 };
 
 // what the reference's converters make of a float sample at bias 384 (src/AC3ASM.asm:303-318: psubd, packssdw)
@@ -84,7 +90,9 @@ __device__ __forceinline__ void load_short(const float *plane, int l8, float sig
     }
 }
 
-template <bool MIX, int WPS, bool S16 = false>
+// MS: with liba52's surround-tail bookkeeping (XformParams::mix_pending), a variant of its own so that the plain mixing
+// kernel keeps its registers and its speed
+template <bool MIX, int WPS, bool S16 = false, bool MS = false>
 __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
 {
     __shared__ float2 lds_ex[4 * EX_WAVE];
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
     for (int oo = 0; oo < 6; oo++) wsl = oo == o ? P.wslot[oo] : wsl;      // (no per-lane indexing of kernel arguments)
     const int tbase = sl * 256 * P.n_out + wsl;
     // MIX: the input planes of this output as a packed list (3 bits each) with their signs
-    uint32_t plist = 0, psign = 0;
+    uint32_t plist = 0, psign = 0, psurr = 0;     // psurr: entry k is a surround plane (mix-state bookkeeping)
     int pcnt = 0;
     if (MIX) {
 #pragma unroll
@@ -149,10 +157,33 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
                 if (oo == o && c < P.n_in && m) {
                     plist |= (uint32_t)c << (3 * pcnt);
                     psign |= (m < 0 ? 1u : 0u) << pcnt;
+                    psurr |= ((P.surr_mask >> c) & 1u) << pcnt;
                     pcnt++;
                 }
             }
     }
+
+    // ---- liba52's treatment of the surround channels' overlap tails around frames with slev == 0 (decode paths only) ----
+    // liba52 keeps an overlap plane per coded channel and mixes in the time domain when the channels of a block differ in
+    // block size ("path A", parse.c:884-916) or mixes coefficients and overlap planes first ("path B", :917-937, flag
+    // `downmixed`).  With slev == 0 it leaves the surround channels out of transform and mix altogether: in path A their
+    // overlap planes stay as they are (and come back when the level does), in path B with the planes not yet mixed they
+    // are dropped.  The engine mixes linearly and keeps one tail per OUTPUT, so it holds the surround planes' share of the
+    // tail apart whenever the next frame could be such a frame - P.mix_pending, written at a frame's last block - and then
+    // lets it join, wait or vanish as liba52's planes would.
+    constexpr bool mixstate = MIX && MS;
+    float *pptr = nullptr;
+    int32_t *fptr = nullptr;
+    bool dm_flag = true, pend = false;
+    if (mixstate) {
+        const size_t sidx = (size_t)(P.slot ? P.slot[s] : s);
+        pptr = P.mix_pending + sidx * P.delay_stride + (size_t)o * 128;
+        fptr = P.mix_flags + sidx * 6 + o;
+        const int fl = *fptr;
+        dm_flag = fl & 1;
+        pend = (fl >> 1) & 1;
+    }
+    const uint32_t fbw_planes = ((1u << P.nfchans) - 1u) << P.in_lfe;
 
     const int nblk = P.nblk;
     const int b_lo = seg * P.seg_blocks, b_hi = b_lo + P.seg_blocks < nblk ? b_lo + P.seg_blocks : nblk;
@@ -196,35 +227,75 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
                 for (int fb = 0; fb < 5; fb++)
                     if (fb < P.nfchans) swm |= (q[fb] ? 1u : 0u) << (fb + P.in_lfe);
             }
-            float xa[16], xb[16];
-            bool any;
+            bool split = false;
+            if (mixstate) {
+                const int fcur = b / 6;
+                const uint8_t *zf = P.zs ? P.zs + (size_t)s * P.frames + fcur : nullptr;
+                const int zs_now = zf ? zf[0] : 0;
+                const uint32_t sf = swm & fbw_planes;
+                const bool path_a = !P.downmixing || (sf != 0 && sf != fbw_planes);
+                if (pend) {
+                    if (!zs_now || dm_flag) {           // the surround planes are transformed again, or were mixed in already
 #pragma unroll
-            for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
-            any = false;
-#pragma unroll 1
-            for (int k = 0; k < 6; k++) {
-                if (k >= pcnt) continue;
-                const int c = (plist >> (3 * k)) & 7;
-                if ((swm >> c) & 1) continue;
-                load_long(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
-                any = true;
+                        for (int j = 0; j < 8; j++) {
+                            const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+                            const volatile float *pv = pptr + 2 * i;      // (this wavefront may have written it a block ago)
+                            dl[j].x += pv[0];
+                            dl[j].y += pv[1];
+                        }
+                        pend = false;
+                    } else if (!path_a) {
+                        pend = false;                   // path B mixes the overlap planes without the surrounds: gone
+                    }                                   // path A: the planes wait
+                }
+                dm_flag = !path_a;
+                // a frame's last block: the surround share of the new tail goes aside unless the next frame is known to mix it
+                split = !zs_now && psurr != 0 && b - 6 * fcur == 5 && (fcur + 1 >= P.frames || zf[1] != 0 || !P.zs);
             }
-            if (any) imdct_long(xa, xb, twl, ex, l8, ft);
-            if (swm) {
+            float xa[16], xb[16];
+            // entries of the plane list to take: all; or, for a split block, first the surround planes, then the others
+#pragma unroll 1
+            for (int pass = (mixstate && split) ? 0 : 1; pass < 2; pass++) {
+                const uint32_t take = (mixstate && split) ? (pass == 0 ? psurr : ~psurr) : ~0u;
+                bool any;
 #pragma unroll
                 for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
                 any = false;
 #pragma unroll 1
                 for (int k = 0; k < 6; k++) {
-                    if (k >= pcnt) continue;
+                    if (k >= pcnt || !((take >> k) & 1)) continue;
                     const int c = (plist >> (3 * k)) & 7;
-                    if (!((swm >> c) & 1)) continue;
-                    load_short(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
+                    if ((swm >> c) & 1) continue;
+                    load_long(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
                     any = true;
                 }
-                if (any) {
-                    const float2 *tws = P.tw_short + l8 * 16;
-                    imdct_short(xa, xb, tws, ex, l8, ft);
+                if (any) imdct_long(xa, xb, twl, ex, l8, ft);
+                if (swm) {
+#pragma unroll
+                    for (int n = 0; n < 16; n++) xa[n] = xb[n] = 0.f;
+                    any = false;
+#pragma unroll 1
+                    for (int k = 0; k < 6; k++) {
+                        if (k >= pcnt || !((take >> k) & 1)) continue;
+                        const int c = (plist >> (3 * k)) & 7;
+                        if (!((swm >> c) & 1)) continue;
+                        load_short(cblk + (size_t)c * 256, l8, ((psign >> k) & 1) ? -1.f : 1.f, xa, xb);
+                        any = true;
+                    }
+                    if (any) {
+                        const float2 *tws = P.tw_short + l8 * 16;
+                        imdct_short(xa, xb, tws, ex, l8, ft);
+                    }
+                }
+                if (mixstate && split && pass == 0) {   // the surround planes' tail: aside, and out of the chain's own tail
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
+                        volatile float *pv = pptr + 2 * i;
+                        if (active) { pv[0] = ft.t0[j]; pv[1] = ft.t1[j]; }
+                        ft.t0[j] = ft.t1[j] = 0.f;
+                    }
+                    pend = true;
                 }
             }
         }
@@ -276,6 +347,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             const int i = ((j & 1) ? 15 - l8 : l8) + 16 * (j >> 1);
             *reinterpret_cast<float2 *>(dptr + 2 * i) = dl[j];
         }
+        if (mixstate && l8 == 0) *fptr = (dm_flag ? 1 : 0) | (pend ? 2 : 0);
     }
 }
 
@@ -298,6 +370,19 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     P.n_out = L.plan.n_out;
     P.nfchans = L.plan.nfchans;
     P.in_lfe = L.plan.in_lfe;
+    P.zs = L.zs;
+    P.mix_pending = L.mix_pending;
+    P.mix_flags = L.mix_flags;
+    P.surr_mask = L.plan.surr_mask;
+    {
+        int out_fbw = L.plan.n_out;
+        if (L.plan.n_out > 0 && L.plan.in_lfe && L.plan.mix[0][0] == 1) {        // output plane 0 is the LFE plane
+            bool only_lfe = true;
+            for (int c = 1; c < L.plan.n_in; c++) only_lfe = only_lfe && L.plan.mix[0][c] == 0;
+            if (only_lfe) out_fbw--;
+        }
+        P.downmixing = out_fbw < L.plan.nfchans ? 1 : 0;
+    }
     P.bias = L.bias;
     bool identity = (L.plan.n_in == L.plan.n_out);
     for (int o = 0; o < 6; o++)
@@ -307,8 +392,10 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
         }
     if (P.n_chains <= 0 || P.frames <= 0) return hipSuccess;
     // enough 8-lane groups to fill the chip (256 CUs x 4 workgroups x 32 groups): cut long chains into whole-frame segments
+    const bool mixstate = !identity && P.mix_pending && P.mix_flags && P.surr_mask;
+    if (!mixstate) P.mix_pending = nullptr;
     P.n_seg = 1;
-    if (P.frames > 1 && P.n_chains < 32768) {
+    if (P.frames > 1 && P.n_chains < 32768 && !mixstate) {       // (the mix-state bookkeeping walks a stream's blocks in order)
         int want = (32768 + P.n_chains - 1) / P.n_chains;
         if (want > P.frames) want = P.frames;
         const int frames_per_seg = (P.frames + want - 1) / want;
@@ -335,12 +422,16 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
         for (int w = 0; w < P.n_out; w++) P.wslot[map[w]] = (int8_t)w;
         if (identity)
             hipLaunchKernelGGL((xform_kernel<false, 3, true>), dim3(grid), dim3(256), 0, stream, P);
+        else if (mixstate)
+            hipLaunchKernelGGL((xform_kernel<true, 2, true, true>), dim3(grid), dim3(256), 0, stream, P);
         else
             hipLaunchKernelGGL((xform_kernel<true, 2, true>), dim3(grid), dim3(256), 0, stream, P);
         return hipGetLastError();
     }
     if (identity)
         hipLaunchKernelGGL((xform_kernel<false, 4>), dim3(grid), dim3(256), lds_pad, stream, P);
+    else if (mixstate)
+        hipLaunchKernelGGL((xform_kernel<true, 2, false, true>), dim3(grid), dim3(256), 0, stream, P);
     else        // 167 VGPRs with the planes of an output accumulated one after the other (187 with their loads unrolled): 3 workgroups per CU
         hipLaunchKernelGGL((xform_kernel<true, 3>), dim3(grid), dim3(256), 0, stream, P);
     return hipGetLastError();

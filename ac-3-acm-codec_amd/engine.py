@@ -227,6 +227,21 @@ class Engine:
         with the transform fused in (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
+    def set_mix_state(self, pending=None, flags=None):
+        """liba52's overlap bookkeeping around frames with surround level 0 (ac3mi_set_mix_state): `pending` float32 shaped
+        like the delay array, `flags` int32 [S][6], both zero for new streams and updated in place by the decode calls that
+        follow; None, None returns to the plain linear mix.  The tensors must stay alive while set."""
+        if (pending is None) != (flags is None):
+            raise ValueError("set_mix_state: give both arrays or neither")
+        if pending is not None:
+            import torch
+            assert pending.dtype == torch.float32 and flags.dtype == torch.int32 and pending.is_cuda and flags.is_cuda
+            torch.cuda.current_stream().synchronize()        # their zero fill was queued on torch's stream
+        self._mix_state = (pending, flags)
+        self._check(self.lib.ac3mi_set_mix_state(ctypes.c_void_p(self.ctx),
+                                                 ctypes.c_void_p(pending.data_ptr() if pending is not None else 0),
+                                                 ctypes.c_void_p(flags.data_ptr() if flags is not None else 0)))
+
     def transcode_batch(self, dec, enc, frames, delay, lfsr, chmap, last, csnroffst, out=None, status=None, wait_torch=True):
         """frames [S][F][in_stride] u8 -> re-encoded frames [S][F][out_stride] u8 (+ status [S][F]); the state arrays
         are those of decode_batch (delay, lfsr) and encode_batch (last, csnroffst), all updated in place."""

@@ -108,6 +108,21 @@ typedef struct {
  * d_lfsr 1, d_last 6*256 samples, d_csnroffst 1.  Pass NULL to return to "stream s uses entry s". */
 int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
 
+/* Optional second overlap state for liba52's exact behaviour around frames whose surround mix level is 0 (new).
+ * liba52 keeps one overlap plane per CODED channel and, when a frame's surmixlev is "no surround", leaves the surround
+ * channels out of transform and mix altogether (a52dec-0.7.5-cvs/liba52/parse.c:900-913, downmix.c:494-583: the slev == 0
+ * cases of MONO, STEREO and 3F outputs): their overlap tails are then dropped, or wait in their planes until the level
+ * comes back, depending on which of a52_block's two synthesis paths runs (parse.c:884-937).  The engine keeps one overlap
+ * tail per OUTPUT channel (d_delay), mixed; with this state it holds the surround channels' share apart where liba52's
+ * bookkeeping can make a difference and reproduces it.  d_pending: laid out and indexed exactly like d_delay
+ * ([n_streams][n_out][128] floats, or slot strides of 6*128 under ac3mi_set_state_slots); d_flags: 6 int32 per stream
+ * (or slot).  Both zero-initialised for a new stream (as after a52_init).  Used by the following ac3mi_decode_batch /
+ * ac3mi_decode_s16_batch / ac3mi_transcode_batch calls whose request mixes surround channels into MONO, STEREO or 3F;
+ * ignored otherwise.  Pass NULL, NULL (the default) for a plain linear mix: identical output unless a stream CHANGES its
+ * surround mix level to or from "no surround" between two frames, and then different only in the 256 samples per channel
+ * that follow the change.  The byte-stream layer and the a52_* drop-in always use it. */
+int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
+
 /* How ac3mi_decode_batch / ac3mi_decode_s16_batch / ac3mi_transcode_batch spread the work over the GPU (new):
  *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame),
  *      coefficient planes go through HBM to the transform kernel;

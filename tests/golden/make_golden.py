@@ -77,7 +77,31 @@ def make_ac3tab():
     print("ac3tab.npz", os.path.getsize(os.path.join(OUT, "ac3tab.npz")), {k: v.shape for k, v in d.items()})
 
 
+MIXFLIP = (("a7_st", 7, 2, (1, 1, 2, 2, 0, 0, 2, 1)), ("a7_mono", 7, 1, (0, 2, 2, 1, 2, 0)), ("a7_dolby", 7, 10, (3, 2, 0, 2, 2, 1)),
+           ("a6_st", 6, 2, (1, 2, 2, 0, 2, 1)), ("a5_st", 5, 2, (0, 2, 1, 2, 2, 3)), ("a4_mono", 4, 1, (1, 2, 0, 2, 2, 1)))
+
+
+def make_mixflip():
+    """Streams whose surmixlev changes between frames (tests/packer.make_flip_stream), decoded by the real liba52."""
+    from tests import packer
+    assert H.have_ref()
+    d = {}
+    for tag, acmod, flags, levels in MIXFLIP:
+        fr = packer.make_flip_stream(2600 + acmod + flags, levels, acmod=acmod)
+        pcm, errs, oflags = H.ref_decode(fr, flags, 1.0, 0.0)
+        assert errs == 0
+        d["frames_" + tag] = fr
+        d["pcm_" + tag] = pcm
+        d["args_" + tag] = np.array([flags, oflags], np.int32)
+        d["levels_" + tag] = np.array(levels, np.int32)
+    np.savez_compressed(os.path.join(OUT, "mixflip.npz"), **d)
+    print("mixflip.npz", os.path.getsize(os.path.join(OUT, "mixflip.npz")))
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "mixflip":
+        make_mixflip()
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "ac3tab":
         make_ac3tab()
         return
@@ -197,6 +221,7 @@ def main():
         d["pcm_" + tag] = pcm
         d["args_" + tag] = np.array([flags, oflags], np.int32)
     np.savez_compressed(os.path.join(OUT, "packer.npz"), **d)
+    make_mixflip()
 
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):

@@ -352,3 +352,12 @@ def make_stream(seed, nframes, acmod, lfeon, **kw):
     feats.setdefault("cmixlev", int(rng.integers(0, 4)))
     feats.setdefault("surmixlev", int(rng.integers(0, 4)))
     return np.stack([make_frame(rng, acmod, lfeon, features=feats, **kw) for _ in range(nframes)])
+
+
+def make_flip_stream(seed, surmixlevs, acmod=7, lfeon=0, **kw):
+    """A stream whose surround mix level changes from frame to frame (surmixlevs: one 2-bit code per frame; code 2 = "no
+    surround", level 0).  Valid AC-3, never seen in practice - and the one case where liba52's per-channel overlap
+    planes and time-domain mixer (parse.c:884-937, downmix.c:559-562) do not behave like a linear mix."""
+    rng = np.random.default_rng(seed)
+    cmix = int(rng.integers(0, 4))
+    return np.stack([make_frame(rng, acmod, lfeon, features={"cmixlev": cmix, "surmixlev": int(lv)}, **kw) for lv in surmixlevs])

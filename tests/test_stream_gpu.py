@@ -9,6 +9,7 @@ the reference holds no fixtures for it.  What is pinned:
     two convert functions (call-by-call src_used / dst_used),
   * n streams advanced together (one batched launch per round) end exactly as n separate streams."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -271,3 +272,28 @@ def test_slot_reuse_starts_clean(S, pool):
         got = np.frombuffer(dst.tobytes(), np.int16).astype(np.int32)
         assert int(np.abs(got - want).max()) <= 1
         st.close()
+
+
+def test_decode_downmix_follows_liba52_through_a_surround_level_change(S, pool):
+    """The pool carries ac3mi_set_mix_state for every slot: a 3/2 stream whose surmixlev goes to "no surround" and back,
+    decoded to stereo through the stream layer, gives liba52's samples (tests/test_mixlevel_switch.py has the details)."""
+    d = np.load(os.path.join(H.GOLDEN, "mixflip.npz"), allow_pickle=False)
+    frames = d["frames_a7_st"]
+    fb = frames.shape[1]
+    rc, st = pool.open(S.ac3_format(5, 48000, fb // 4, block_align=fb), S.pcm_format(2, 48000), S.ACM_DYNAMICRANGE)
+    assert rc == 0
+    out = bytearray()
+    for f in range(len(frames)):                  # a frame per call, as a live stream arrives
+        src = frames[f].copy()
+        dst = np.zeros(6 * 256 * 2 * 2, np.uint8)
+        h = S.StreamHeader(src.ctypes.data, fb, 0, dst.ctypes.data, dst.size, 0, S.STREAMCONVERTF_START if f == 0 else 0)
+        assert st.convert(h) == 0 and h.src_used == fb
+        out += dst[:h.dst_used].tobytes()
+    st.close()
+    want = _oracle_s16(frames, 2).reshape(-1)
+    g = np.frombuffer(bytes(out), np.int16)
+    assert g.size == want.size
+    # random mantissas: loud, many saturated samples, and the sum of five planes is rounded in another order than liba52's
+    # time-domain mix - two s16 steps (two float32 ulps at bias 384) at a handful of samples; a missed quirk is hundreds
+    diff = np.abs(g.astype(np.int32) - want)
+    assert int(diff.max()) <= 2 and int((diff > 1).sum()) <= diff.size // 200
