@@ -33,6 +33,22 @@ namespace ac3mi {
 #ifndef DEC_LB
 #define DEC_LB 5
 #endif
+// Measurement aid (make EXTRA=-DDEC_STAMPS, a separate library): lane 0 of every wavefront adds the s_memtime cycles of
+// a frame's sections to g_dec_cycles: 0 staging + header, 1 side information, 2 exponents, 3 bit-allocation parameters +
+// bit allocation, 4 mantissas (+ coupling, rematrix, stores), 5 the rest.  ac3mi_debug_dec_cycles reads them.
+#ifdef DEC_STAMPS
+__device__ unsigned long long g_dec_cycles[8];
+#define DK_DECL() unsigned long long dk_t = 0, dk_acc[6] = {0, 0, 0, 0, 0, 0}
+#define DK_T0() dk_t = __builtin_readcyclecounter()
+#define DK_LAP(id) do { const unsigned long long t_ = __builtin_readcyclecounter(); dk_acc[id] += t_ - dk_t; dk_t = t_; } while (0)
+#define DK_END() do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_dec_cycles[i_], dk_acc[i_]); } while (0)
+#else
+#define DK_DECL() do { } while (0)
+#define DK_T0() do { } while (0)
+#define DK_LAP(id) do { } while (0)
+#define DK_END() do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P)
 {
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
     for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
     st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
+    DK_DECL();
     st.lfsr = MODE == 0 ? (uint32_t)P.lfsr_state[sslot]
             : MODE == 2 ? (uint32_t)P.frame_lfsr[(size_t)s * P.frames_per_stream + f_first] : 1u;
     int hth_fscod = -1;
@@ -85,6 +102,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
         // what it reuses is whatever the variant at hand has carried so far, so results may depend on the batch shape
         bool reuse0 = false;
 
+        DK_T0();
         // ---- stage the frame: byte-swapped dwords, zero padded ----
         {
             const int nw = (P.frame_bytes + 3) >> 2;
@@ -166,6 +184,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
         if (!hdr_ok) status |= 0x100u | 0x3fu;
 
         bool frame_dead = !hdr_ok;
+        DK_LAP(0);
         for (int blk = 0; blk < 6; blk++) {
             float *cblk = cout + (size_t)blk * P.n_in * 256;
             const int in_lfe = P.lfeon ? 1 : 0;
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
                     }
                 if (err) break;
 
+                DK_LAP(1);
                 // ---- exponents: parse.c:703-736 ----
                 int redo = 0;
                 if (cplexpstr) {
@@ -285,6 +305,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
                     rd.pos += 14;
                 }
 
+                DK_LAP(2);
                 // ---- bit-allocation parameters: parse.c:738-772 ----
                 if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
                 else if (blk == 0) reuse0 = true;
@@ -410,6 +431,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
             }
 
             if (!err) {
+                DK_LAP(3);
                 // ---- gains: parse.c:810-811 ----
                 a52_downmix_coeff_hd(gain, st.acmod, st.output, st.dynrng, st.clev, st.slev);
 
@@ -542,6 +564,7 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
                 if (MODE != 1 && lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
             }
 
+            DK_LAP(4);
             // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
             if (MODE != 1) {
@@ -554,11 +577,13 @@ __global__ __launch_bounds__(64, DEC_LB) void decode_kernel(const DecodeParams P
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        DK_LAP(5);
         if (MODE != 1 && lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
         if (MODE != 1 && lane == 0 && P.zs) P.zs[fidx] = (uint8_t)((status & 0x100u) ? 0 : surround_level_is_zero(st.acmod, st.output, st.slev));
         if (MODE == 1 && lane == 0) P.frame_draws[fidx] = frame_draws;
     }
     if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
+    DK_END();
     if (MODE == 2 && lane == 0 && f_end == P.frames_per_stream) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
 }
 
@@ -581,6 +606,17 @@ __global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, 
 }  // namespace ac3mi
 
 namespace ac3mi {
+
+#ifdef DEC_STAMPS
+}  // namespace ac3mi
+extern "C" __attribute__((visibility("default"))) int ac3mi_debug_dec_cycles(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ac3mi::g_dec_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ac3mi::g_dec_cycles), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+namespace ac3mi {
+#endif
 
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream)
 {
