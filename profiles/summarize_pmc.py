@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 out, tag, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
@@ -23,7 +24,9 @@ def rows(pattern):
 
 def short(name):
     name = name.replace("void ", "").replace("ac3mi::", "")
-    return name.split("(")[0].strip()
+    name = name.split("(")[0].strip()
+    # xform_kernel<MIX, WPS, S16, MS>: the plain kernels keep their three-parameter names
+    return re.sub(r"(xform_kernel<\w+, \d+, \w+), false>", r"\1>", name)
 
 
 def per_kernel(pattern, counters):
