@@ -608,6 +608,40 @@ int ac3mi_probe_salu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd)
     return AC3MI_OK;
 }
 
+// one float4 per lane and the workgroup ends: the copy the guide quotes (MI355X_MICROARCH.md, HBM) and the fastest one
+// measured on this part (profiles/hbm_calibrate)
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+
+int ac3mi_probe_copy_rate(ac3mi_ctx *ctx, size_t bytes, double *gbytes_per_s)
+{
+    if (!ctx || !gbytes_per_s || bytes < (1u << 20)) return AC3MI_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&a, n * 16));
+    if (hipMalloc((void **)&b, n * 16) != hipSuccess) { (void)hipFree(a); ctx->err = "ac3mi_probe_copy_rate: out of memory"; return AC3MI_ERR_HIP; }
+    (void)hipMemsetAsync(a, 0, n * 16, ctx->stream);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    float best = 1e30f;
+    for (int it = 0; it < 6; it++) {
+        (void)hipEventRecord(ctx->ev0, ctx->stream);
+        hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, n);
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        if (hipEventSynchronize(ctx->ev1) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess && it > 0 && ms < best) best = ms;
+    }
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (best > 1e29f) { ctx->err = "ac3mi_probe_copy_rate: timing failed"; return AC3MI_ERR_HIP; }
+    *gbytes_per_s = 2.0 * (double)(n * 16) / (best * 1e-3) / 1e9;
+    return AC3MI_OK;
+}
+
 int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots)
 {
     if (!ctx) return AC3MI_ERR_ARG;

@@ -212,6 +212,12 @@ class Engine:
         self._check(self.lib.ac3mi_probe_valu_rate(ctypes.c_void_p(self.ctx), ctypes.byref(v)))
         return v.value
 
+    def probe_copy_rate(self, nbytes=1 << 31):
+        """GB/s (read + written) of a bare one-float4-per-lane copy of nbytes (ac3mi_probe_copy_rate)."""
+        v = ctypes.c_double(0.0)
+        self._check(self.lib.ac3mi_probe_copy_rate(ctypes.c_void_p(self.ctx), ctypes.c_size_t(int(nbytes)), ctypes.byref(v)))
+        return v.value
+
     def probe_salu_rate(self):
         """10^9 scalar instructions/s one SIMD's share of the scalar unit sustains under a chip-wide load (ac3mi_probe_salu_rate)."""
         v = ctypes.c_double()

@@ -613,6 +613,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
 
+    # the guide's float4 copy on this box in this run: what a read+write stream reaches at best (rank 0, untimed)
+    copy_gbs = None
+    if rank == 0:
+        try:
+            copy_gbs = eng.probe_copy_rate(1 << 31)
+        except Exception:                                   # (an older library: the line simply lacks the field)
+            copy_gbs = None
+
     # ---- secondary timings (not the headline): full frame decode, encode, transcode ----
     extra = None
     if not args.no_extra:
@@ -656,6 +664,10 @@ def main():
                 "kernel": "ac3mi::xform_kernel<false, 4, false>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
+                "copy_probe": None if not copy_gbs else {
+                    "GBps": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+                    "note": "bare float4 copy, one element per lane, 2 GiB per array, measured in this run "
+                            "(ac3mi_probe_copy_rate): the practical ceiling of a read+write stream on this box; `peak` stays the spec number"},
             },
         }
         if extra is not None:
