@@ -907,7 +907,10 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
     const int fs = P.frame_words;
 
     const int sslot = P.slot ? P.slot[s] : s;
-    int csnr_prev = PART == 2 ? 0 : P.csnr_state[sslot];
+    // the stream's search state: csnroffst in bits 0-7, the fsnroffst of its last coded frame in bits 8-11 (what the
+    // reference's s->csnroffst / s->fsnroffst[] hold between frames, ENC/ac3enc.cpp:969-972)
+    const int state_in = PART == 2 ? 0 : P.csnr_state[sslot];
+    int csnr_prev = state_in & 0xff, fsnr_prev = (state_in >> 8) & 15;
     PK_DECL();
 
     for (int f = f_first; f < f_end; f++) {
@@ -982,7 +985,12 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
         //      and everything after the first surprise is discarded. ----
         const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&L.band_of_bin[4 * lane]);    // bands of bins 4*lane..+3
         SnrSearch ss{csnr_prev, 0, 0, false};
-        if (PART == 2) { ss.csnr = P.snr[fidx * 2]; ss.fsnr = P.snr[fidx * 2 + 1]; ss.phase = 5; }      // PART 1 found them
+        int alloc_override = -1;        // PART 2: the allocation offset of a frame whose search failed (see below)
+        if (PART == 2) {                // PART 1 found them
+            const int w1 = P.snr[fidx * 2 + 1];
+            ss.csnr = P.snr[fidx * 2]; ss.fsnr = w1 & 15; ss.phase = 5;
+            if (w1 & 0x100) alloc_override = w1 >> 9;
+        }
         // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
         // known_f / fits_f for (csnroffst f_cc, ff > 0).  The reference asks for some offsets twice.
         uint64_t known_c = 0, fits_c = 0;
@@ -1139,16 +1147,29 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             continue;
         }
         int csnr = ss.csnr, fsnr = ss.fsnr;
-        if (!ss.failed) csnr_prev = csnr;
-        else { csnr = 0; fsnr = 0; }        // reference: error path, out of contract for every supported bit rate
-        const int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
+        int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
+        int failed_alloc = alloc_override;
+        if (PART != 2) {
+            if (!ss.failed) { csnr_prev = csnr; fsnr_prev = fsnr; }
+            else {
+                // The reference's error path ("Yack, Error !!!", :930-933), reached when the start value and every start value
+                // minus a multiple of 4 down to 0..3 fail - even if an offset in between would fit: compute_bit_allocation
+                // returns without touching s->csnroffst / s->fsnroffst, its caller ignores the result (:1752), the header
+                // carries the previous frame's offsets and the mantissas follow the allocation of the LAST attempt,
+                // (start & 3, 0).  Such a frame overflows; the reference writes on, the engine drops what is beyond its buffer.
+                failed_alloc = csnr_prev & 3;
+                csnr = csnr_prev;
+                fsnr = fsnr_prev;
+            }
+        }
+        if (failed_alloc >= 0) snroffset = ((failed_alloc - 15) << 4) << 2;
         if (P.tap_snr && lane == 0) { P.tap_snr[fidx * 2] = csnr; P.tap_snr[fidx * 2 + 1] = fsnr; }
         if (P.tap_strat && lane < 36) {
             const int b = lane / 6, ch = lane - 6 * b;
             if (ch < nch) P.tap_strat[(fidx * 6 + b) * nch + ch] = L.strat[b][ch];
         }
         if (PART == 1) {                    // the packer of this frame is another wavefront
-            if (lane == 0) { P.snr[fidx * 2] = csnr; P.snr[fidx * 2 + 1] = fsnr; }
+            if (lane == 0) { P.snr[fidx * 2] = csnr; P.snr[fidx * 2 + 1] = fsnr | (failed_alloc >= 0 ? 0x100 | (failed_alloc << 9) : 0); }
             continue;
         }
 
@@ -1428,7 +1449,7 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
         WAVE_SYNC();
         PK_LAP(3);
     }
-    if ((PART == 0 || PART == 1) && lane == 0) P.csnr_state[sslot] = csnr_prev;
+    if ((PART == 0 || PART == 1) && lane == 0) P.csnr_state[sslot] = csnr_prev | (fsnr_prev << 8);
     PK_END();
 }
 

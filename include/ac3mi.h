@@ -302,8 +302,10 @@ int ac3mi_encode_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *ht
  * chmap        HOST array, `channels` entries: input slot of coded channel ch (AC3_encode_frame's `chmap`;
  *              the driver passes {0,2,1,4,5,3} for 6-channel WAVE order, src/AC3ACM.cpp:1631-1662)
  * d_last       [n_streams][channels][256] s16: last_samples (ENC/ac3enc.cpp:55), read and rewritten
- * d_csnroffst  [n_streams] int32: coarse SNR offset the search starts from (AC3_encode_init sets 40,
- *              :1092; each frame stores its result, :969), read and rewritten
+ * d_csnroffst  [n_streams] int32: the stream's search state, read and rewritten: bits 0-7 the coarse SNR offset the search
+ *              starts from (AC3_encode_init sets 40, :1092; each frame stores its result, :969), bits 8-11 the fine SNR
+ *              offset of the last frame whose search succeeded (s->fsnroffst[], :970-972; 0 for a new stream, so
+ *              initialise the word to 40) - a frame whose search fails repeats both in its header (:930-933, :1752)
  * d_frames     [n_streams][frames_per_stream] frames, frame_stride bytes apart (multiple of 4)
  */
 int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int16_t *d_pcm,

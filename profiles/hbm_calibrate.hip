@@ -173,6 +173,24 @@ __global__ __launch_bounds__(256) void copy_streams_flat(const float4 *__restric
     }
 }
 
+// (e) block-parallel: an 8-lane group per (chain, block) row, a workgroup of 8 * cpw * 6 lanes takes cpw chains of one-frame
+//     streams (6 blocks each), moves its rows in one go and ends (what a transform that passes the overlap tails through LDS
+//     instead of walking a chain would read and write)
+__global__ void copy_rows_blockpar(const float2 *__restrict__ a, float2 *__restrict__ b, int n_chains, int cpw)
+{
+    extern __shared__ float pad_[];
+    const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const int chain = blockIdx.x * cpw + g / 6, blk = g - 6 * (g / 6);
+    if (g >= 6 * cpw || chain >= n_chains) return;
+    const int s = chain / 6, o = chain - 6 * s;
+    const size_t base = (((size_t)s * 6 + blk) * 6 + o) * 128 + l8;
+    float2 v[16];
+#pragma unroll
+    for (int n = 0; n < 16; n++) v[n] = a[base + 8 * n];
+#pragma unroll
+    for (int n = 0; n < 16; n++) b[base + 8 * n] = v[n];
+}
+
 // ---- issue probes: 8 wavefronts per SIMD, nothing but register arithmetic --------------------------------------
 __global__ __launch_bounds__(256) void salu_probe(uint32_t *out, int iters)
 {
@@ -311,6 +329,13 @@ int main()
             const int f4 = kb * 64, g2 = (int)(bytes / 16 / f4);
             double ms = time_ms([&] { hipLaunchKernelGGL(copy_streams_flat, dim3(g2), dim3(256), 0, 0, a, b, g2, 1, f4); });
             printf("contiguous %2d KB per workgroup, then the workgroup ends: %.3f ms  %.0f GB/s\n", kb, ms, 2.0 * (double)g2 * f4 * 16 / ms / 1e6);
+        }
+        for (int cpw : {1, 2, 4, 5, 8}) {
+            const int threads = ((8 * 6 * cpw + 63) / 64) * 64, g3 = (chains + cpw - 1) / cpw;
+            for (int lds : {0, 20000, 40000}) {
+                double ms = time_ms([&] { hipLaunchKernelGGL(copy_rows_blockpar, dim3(g3), dim3(threads), lds, 0, (const float2 *)a, (float2 *)b, chains, cpw); });
+                printf("block-parallel rows, %d chain(s) x 6 blocks per workgroup of %3d lanes, %5d B LDS: %.3f ms  %.0f GB/s\n", cpw, threads, lds, ms, 2.0 * bytes / ms / 1e6);
+            }
         }
         for (int spw : {1, 2, 4, 8}) {
             for (int lds : {0, 40960}) {

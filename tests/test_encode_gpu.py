@@ -240,6 +240,39 @@ def test_starved_bit_rate_is_survivable(engine):
     assert np.array_equal(got, want)
 
 
+def test_failed_search_follows_the_reference(engine):
+    """3 channels at 48 kbps / 24 kHz: the previous frame's csnroffst (3) does not fit the next frame and 3 - 4 is negative,
+    so the reference's search gives up ("Yack, Error !!!", ac3enc.cpp:921-933) although csnroffst 0..2 would fit:
+    compute_bit_allocation returns without storing offsets, its caller carries on (:1752) - the header repeats the previous
+    frame's offsets, the mantissas follow the allocation of the last attempt.  Found by tests/fuzz_encode.py (seed 101,
+    round 25).  The engine matches the oracle byte for byte on both batch-shape paths, and the search state it hands back
+    (csnroffst | fsnroffst << 8) lets the next call continue the same way."""
+    import torch
+    pkg = H.pkg()
+    nch, freq, bitrate = 3, 24000, 48000
+    chmap = tuple(range(8))
+    pcm = [H.gen_pcm(4, nch, seed=101000 + 25 * 7 + s, kind=k) for s, k in enumerate(("music", "tones", "tones", "music"))]
+    want, wt = _oracle(pcm, nch, bitrate, freq, chmap)
+    got, gt = _gpu(engine, pcm, nch, bitrate, freq, chmap)
+    snr = wt["snr"].reshape(4, 4, 2)
+    assert np.array_equal(gt["snroffst"].reshape(4, 4, 2), snr)
+    assert np.array_equal(snr[0, 3], snr[0, 2]) and np.array_equal(snr[3, 2], snr[3, 1])     # the two frames that repeat stale offsets
+    assert np.array_equal(got, want), "bitstream differs in %d bytes" % int((got != want).sum())
+    # frame by frame, the state carried by the caller
+    desc = pkg.EncodeDesc(freq, bitrate, nch)
+    x = torch.from_numpy(np.stack(pcm).reshape(4, 4, 1536, nch)).cuda()
+    last = torch.zeros((4, nch, 256), dtype=torch.int16, device="cuda")
+    csnr = torch.full((4,), 40, dtype=torch.int32, device="cuda")
+    parts = []
+    for f in range(4):
+        out = engine.encode_batch(desc, x[:, f:f + 1].contiguous(), chmap[:nch], last, csnr)
+        engine.sync()
+        parts.append(out.cpu().numpy()[:, :, :want.shape[2]])
+    assert np.array_equal(np.concatenate(parts, axis=1), want)
+    st = csnr.cpu().numpy()
+    assert np.array_equal(st & 0xff, snr[:, 3, 0]) and np.array_equal((st >> 8) & 15, snr[:, 3, 1])
+
+
 def test_batch_shape_paths_agree(engine):
     """One call with six frames per stream goes through the tabulate / replay / pack-per-frame kernels; six calls of one
     frame each go through the one-wavefront-per-stream kernel with the state carried by the caller.  Same bytes."""
