@@ -527,11 +527,15 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                         if (slot < 5 && ((st.chincpl >> slot) & 1)) {
                             // a coupled channel: its own bins, zeros up to the coupling range (a damaged frame can leave a gap
                             // there: liba52 then keeps the previous block's PCM, its buffer being transformed in place; here
-                            // zeros) and from its end on; the coupling channel's share in between is written by that segment
+                            // zeros) and from the END OF THE COUPLING RANGE on - also where a damaged frame left the channel's own
+                            // end (it keeps the previous block's when the exponents are reused) beyond it: liba52 zeroes from
+                            // cplendmant (parse.c:826-834).  The coupling channel's share in between is written by that segment,
+                            // which comes after the first coupled channel and before the others: as in liba52, a later coupled
+                            // channel's own bins inside the range win over the coupling channel's, the first one's lose.
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
                                 const int bin = 4 * lane + j;
-                                if (bin < end || bin < st.cplstrtmant || bin >= st.cplendmant) plane[bin] = out[j];
+                                if (bin < end || bin < st.cplstrtmant || bin >= st.cplendmant) plane[bin] = bin >= st.cplendmant ? 0.f : out[j];
                             }
                         } else {
                             *reinterpret_cast<float4 *>(plane + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);

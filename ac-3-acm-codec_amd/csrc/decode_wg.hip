@@ -1046,10 +1046,16 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                         const int8_t *bapc = L.bap + row_off(6);
                         const uint8_t *expc = L.exp + row_off(6);
                         float *plane = L.planes + (wave + in_lfe) * PLANE;
+                        // (a damaged frame can leave a coupled channel's own end - the previous block's, when it reuses its
+                        // exponents - inside or beyond the coupling range: liba52 decodes the channel's own bins, writes the
+                        // coupling channel's share when it meets the FIRST coupled channel, zeroes every coupled channel from
+                        // cplendmant on (parse.c:813-834); so a later coupled channel's own bins inside the range stay)
+                        const int cplfirst = __builtin_ctz(chincpl), own_end = ldsu(B.endmant[wave < 5 ? wave : 0]);
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const int bin = 4 * lane + j;
-                            if (bin >= cplstrt && bin < cplend) {
+                            if (bin >= cplend) plane[bin] = 0.f;
+                            if (bin >= cplstrt && bin < cplend && (wave == cplfirst || bin >= own_end)) {
                                 const int bnd = B.cplbnd[(bin - cplstrt) / 12];
                                 const float co = B.cplco[wave < 5 ? wave : 0][bnd] * gc;
                                 const int w = bapc[bin], e = expc[bin];

@@ -51,7 +51,10 @@ def make_damaged(seed, acmod, lfe, S=96, fscod=0, bsid=8, frmsizecod=30, base_st
         buf[:fb] = frames[s]
         fl, lv = H.ci(flags), H.cf(1.0)
         rc = L.orc_a52_frame(st, H.P(buf, H.u8p), ctypes.byref(fl), ctypes.byref(lv), 0.0)
-        if rc != 0 or (1 if fl.value & 16 else 0) != lfe:
+        # lfeon as the frame carries it (a52_syncinfo reads the bit; a52_frame only reports it when LFE output was requested)
+        sflags, srate, brate = H.ci(), H.ci(), H.ci()
+        L.orc_a52_syncinfo(H.P(buf, H.u8p), ctypes.byref(sflags), ctypes.byref(srate), ctypes.byref(brate))
+        if rc != 0 or (1 if sflags.value & 16 else 0) != lfe:
             want_foreign[s] = True                       # lfeon flipped: not the batch's configuration
         else:
             for b in range(6):

@@ -297,3 +297,46 @@ def test_decode_downmix_follows_liba52_through_a_surround_level_change(S, pool):
     # time-domain mix - two s16 steps (two float32 ulps at bias 384) at a handful of samples; a missed quirk is hundreds
     diff = np.abs(g.astype(np.int32) - want)
     assert int(diff.max()) <= 2 and int((diff > 1).sum()) <= diff.size // 200
+
+
+def test_rounds_of_thousands_of_streams_cross_pcie_in_chunks(S, engine):
+    """From 2 048 streams of one configuration on, a round's batch is cut into chunks whose copies and kernels overlap
+    (stream.hip, decode_group / encode_group): every stream still gets exactly its own samples / frame, for two rounds in a
+    row (carry-over state through the slot table), decode and encode."""
+    n = 2300
+    pool = S.Pool(engine, 2 * n)
+    try:
+        kinds = ("tones", "music", "noise", "bursts", "quiet", "strobe", "tones")
+        frames = [H.orc_encode(H.gen_pcm(2, 6, seed=300 + i, kind=kinds[i])) for i in range(7)]
+        want_dec = [_oracle_s16(fr, 7 | 16).reshape(2, -1) for fr in frames]                  # per frame
+        pcms = [H.gen_pcm(2, 2, seed=400 + i, kind=kinds[i]) for i in range(7)]
+        want_enc = [H.orc_encode(p, nch=2, bitrate=192000, chmap=(0, 1)) for p in pcms]
+        dec = [pool.open(S.ac3_format(6, 48000, 384, block_align=1536), S.pcm_format(6, 48000))[1] for _ in range(n)]
+        enc = [pool.open(S.pcm_format(2, 48000), S.ac3_format(2, 48000, 192))[1] for _ in range(n)]
+        assert all(s is not None for s in dec + enc)
+        for f in range(2):
+            keep, hs = [], []
+            for i in range(n):
+                src = frames[i % 7][f].copy()
+                dst = np.zeros(6 * 256 * 6 * 2, np.uint8)
+                keep.append((src, dst))
+                hs.append(S.StreamHeader(src.ctypes.data, src.size, 0, dst.ctypes.data, dst.size, 0, S.STREAMCONVERTF_START if f == 0 else 0))
+            for i in range(n):
+                src = np.frombuffer(pcms[i % 7][f * 1536:(f + 1) * 1536].tobytes(), np.uint8).copy()
+                dst = np.zeros(4096, np.uint8)
+                keep.append((src, dst))
+                hs.append(S.StreamHeader(src.ctypes.data, src.size, 0, dst.ctypes.data, dst.size, 0, S.STREAMCONVERTF_START if f == 0 else 0))
+            assert pool.convert_many(dec + enc, hs) == 0
+            for i in range(n):
+                assert hs[i].src_used == hs[i].src_len and hs[i].dst_used == keep[i][1].size
+                g = np.frombuffer(keep[i][1].tobytes(), np.int16).astype(np.int32)
+                assert int(np.abs(g - want_dec[i % 7][f].astype(np.int32)).max()) <= 1, (f, i)
+            for i in range(n):
+                h, (src, dst) = hs[n + i], keep[n + i]
+                w = want_enc[i % 7][f]
+                assert h.src_used == h.src_len and h.dst_used == w.size, (f, i, h.dst_used)
+                assert np.array_equal(dst[:w.size], w), (f, i)
+        for st in dec + enc:
+            st.close()
+    finally:
+        pool.close()
