@@ -453,6 +453,10 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                 const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
                 const bool lfsr_live = st.lfsr != 0;
                 const int remat_end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
+                // Only a damaged frame can put rematrixed bins inside the coupling range (a coupled channel that reuses its
+                // exponents keeps the previous block's end): liba52 rematrixes the planes as they stand after coupling and
+                // zeroing (parse.c:837-865), so that case runs as a pass of its own after the segments.
+                const bool remat_late = st.acmod == 2 && st.rematflg != 0 && st.chincpl != 0 && remat_end > st.cplstrtmant;
                 const int cplfirst = st.chincpl ? __builtin_ctz(st.chincpl) : 99;
                 const int nseg = nf + (st.chincpl ? 1 : 0) + (st.lfeon ? 1 : 0);
                 SegBase sb;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                             out[j] = q * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
                         }
                         float *plane = cblk + (slot == 5 ? 0 : slot + in_lfe) * 256;
-                        if (slot == 1 && st.acmod == 2 && st.rematflg != 0) {
+                        if (slot == 1 && st.acmod == 2 && st.rematflg != 0 && !remat_late) {
                             // rematrix: parse.c:837-865.  Channel 0's bins were stored by this same lane.
                             float4 a4 = *reinterpret_cast<const float4 *>(plane - 256 + 4 * lane);
                             float a[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -516,7 +520,9 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                             for (int j = 0; j < 4; j++) {
                                 const int bin = 4 * lane + j;
                                 const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
-                                if (bin >= 13 && bin < remat_end && ((st.rematflg >> band) & 1)) {
+                                // (liba52's loop is a do-while, parse.c:846-862: with the first band's flag set it rematrixes bin 13
+                                // even when the channels end at or below it - a damaged frame whose block 0 reuses exponents)
+                                if (bin >= 13 && (bin < remat_end || (bin == 13 && remat_end <= 13)) && ((st.rematflg >> band) & 1)) {
                                     const float x = a[j], v = out[j];
                                     a[j] = x + v;
                                     out[j] = x - v;
@@ -564,6 +570,20 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                                 if (in) cblk[(c + in_lfe) * 256 + bin] = v;
                             }
                             cd += zero ? draws : 0;
+                        }
+                    }
+                }
+                if (MODE != 1 && remat_late) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    volatile float *p0 = cblk + (size_t)in_lfe * 256, *p1 = p0 + 256;
+                    for (int bin = 13 + lane; bin < remat_end; bin += 64) {
+                        const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
+                        if ((st.rematflg >> band) & 1) {
+                            const float a = p0[bin], v = p1[bin];
+                            p0[bin] = a + v;
+                            p1[bin] = a - v;
                         }
                     }
                 }

@@ -1069,8 +1069,13 @@ __global__ __launch_bounds__(512, WG_LB) void decode_wg_kernel(const WgParams W)
                         }
                     }
                     const int rematflg = ldsu(B.rematflg);
+                    // (only a damaged frame can put rematrixed bins inside the coupling range: then the coupled channels'
+                    // waves must have finished above before wave 0 reads their planes)
+                    if (rematflg && chincpl && ldsu(B.remat_end) > cplstrt) wg_barrier();
                     if (rematflg && wave == 0) {                     // rematrix: parse.c:837-865 (a coupled channel's share lies above these bins)
-                        const int rend = ldsu(B.remat_end);
+                        // (liba52's loop is a do-while, parse.c:846-862: with the first band's flag set it rematrixes bin 13 even
+                        // when the channels end at or below it - a damaged frame whose block 0 reuses exponents)
+                        const int rend0 = ldsu(B.remat_end), rend = rend0 <= 13 && (rematflg & 1) ? 14 : rend0;
                         float *p0 = L.planes + in_lfe * PLANE, *p1 = p0 + PLANE;
                         for (int bin = 13 + lane; bin < rend; bin += 64) {
                             const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;

@@ -2,7 +2,7 @@
 runs one round of it): packer frames with random bit flips after the acmod field.  For every frame the GPU must report
 the same first failing block as the oracle (a52_block returning 1, L52/parse.c:228-771), produce bit-identical
 coefficient planes for the blocks before it and leave the dither generator where the oracle leaves it.
-    python tests/fuzz_corrupt.py [n_rounds] [seed0]"""
+    python tests/fuzz_corrupt.py [n_rounds] [seed0] [acmod]      (acmod given: every round uses it, e.g. 2 for rematrixing)"""
 import ctypes
 import sys
 
@@ -69,6 +69,15 @@ def make_damaged(seed, acmod, lfe, S=96, fscod=0, bsid=8, frmsizecod=30, base_st
         want_lfsr[s] = L.orc_a52_get_lfsr(st)
         L.orc_a52_free(st)
     want_coef[gap] = 0.0
+    # stereo: rematrixing (parse.c:837-865) mixes a gap bin of one channel - whatever liba52's buffer held - into BOTH
+    # channels: neither is defined there.  `ignore` marks those bins; the caller blanks them on both sides.
+    ignore = np.zeros_like(gap)
+    if acmod == 2:
+        both = gap[:, :, lfe, 13:] | gap[:, :, lfe + 1, 13:]
+        ignore[:, :, lfe, 13:] = both
+        ignore[:, :, lfe + 1, 13:] = both
+    want_coef[ignore] = 0.0
+    make_damaged.ignore = ignore
     return frames, want_coef, want_fail, want_foreign, want_lfsr
 
 
@@ -91,6 +100,7 @@ def damaged_round(eng, seed, acmod, lfe, **kw):
     eng.sync()
     status = status.cpu().numpy()[:, 0]
     got = taps["coef"].cpu().numpy()[:, 0]
+    got[make_damaged.ignore[:, :, :got.shape[2]]] = 0.0
     got_lfsr = lfsr.cpu().numpy().astype(np.int64) & 0xffff
     pcm = pcm.cpu().numpy()[:, 0]
     bad = 0
@@ -116,11 +126,14 @@ def damaged_round(eng, seed, acmod, lfe, **kw):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only_acmod = int(sys.argv[3]) if len(sys.argv) > 3 else None
     eng = H.pkg().Engine(0)
     rng = np.random.default_rng(seed0)
     total = 0
     for r in range(rounds):
         acmod, lfe = int(rng.integers(0, 8)), int(rng.integers(0, 2))
+        if only_acmod is not None:
+            acmod = only_acmod
         fscod, bsid = int(rng.integers(0, 3)), int(rng.choice([8, 8, 9, 10]))
         fsz = int(rng.integers(24, 38))
         try:
