@@ -60,6 +60,10 @@ struct MixPlan {
     // frame's slev is 0 liba52 neither transforms nor mixes them (L52/parse.c:900-913, downmix.c:494-583), which is not a
     // linear mix at level 0 as far as their overlap tails go - see XformLaunch::mix_pending.
     uint8_t surr_mask;
+    // ... and the OUTPUT planes that then come out without the bias when the block takes the per-channel path: for 2/1 and
+    // 2/2 to STEREO and 3/1 and 3/2 to 3F a52_downmix returns at `if (slev == 0) break;` (downmix.c:530-583) before the
+    // mixer that would have added it, and a52_downmix_coeff had told a52_block not to add it in those channels' transforms
+    uint8_t nobias_mask;
 };
 
 struct XformLaunch {

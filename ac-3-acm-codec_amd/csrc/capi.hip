@@ -317,6 +317,8 @@ int build_mix_plan(int acmod, int lfeon, int output, MixPlan *plan)
     if ((A & 4) && (out == AC3MI_MONO || out == AC3MI_STEREO || out == AC3MI_3F)) {
         const int nsurr = A >= 6 ? 2 : 1;
         for (int c = plan->nfchans - nsurr; c < plan->nfchans; c++) plan->surr_mask |= (uint8_t)(1u << (c + plan->in_lfe));
+        if (out == AC3MI_STEREO && !(A & 1)) plan->nobias_mask = (uint8_t)(3u << out_lfe);             // 2/1, 2/2: L and R
+        if (out == AC3MI_3F) plan->nobias_mask = (uint8_t)(5u << out_lfe);                             // 3/1, 3/2: L and R, not C
     }
     return AC3MI_OK;
 }

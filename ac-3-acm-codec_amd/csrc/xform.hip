@@ -52,6 +52,7 @@ struct XformParams {
     float *mix_pending;         // per chain 128 floats, indexed like `delay`
     int32_t *mix_flags;         // per stream slot 6 words (one per output chain): bit 0 `downmixed`, bit 1 share pending
     uint32_t surr_mask;         // input planes that are surround channels mixed at slev
+    uint32_t nobias_mask;       // output planes liba52 leaves without the bias in a per-channel-path block of a frame with slev == 0
     int downmixing;             // fewer full-bandwidth outputs than coded channels (parse.c:881-883)
 };
 
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
         const bool emit = !extra && b >= b_lo;      // the block ahead of a segment only supplies its tail
         const float *cblk = cbase + (size_t)b * in_stride_blk;
         FirstTail ft;
+        float bias_blk = P.bias;
 #pragma unroll
         for (int j = 0; j < 8; j++) ft.f0[j] = ft.f1[j] = ft.t0[j] = ft.t1[j] = 0.f;
 
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
                     if (fb < P.nfchans) swm |= (q[fb] ? 1u : 0u) << (fb + P.in_lfe);
             }
             bool split = false;
+            bias_blk = P.bias;
             if (mixstate) {
                 const int fcur = b / 6;
                 const uint8_t *zf = P.zs ? P.zs + (size_t)s * P.frames + fcur : nullptr;
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
                     }                                   // path A: the planes wait
                 }
                 dm_flag = !path_a;
+                if (zs_now && path_a && ((P.nobias_mask >> o) & 1u)) bias_blk = 0.f;       // liba52 forgets the bias here (MixPlan::nobias_mask)
                 // a frame's last block: the surround share of the new tail goes aside unless the next frame is known to mix it
                 split = !zs_now && psurr != 0 && b - 6 * fcur == 5 && (fcur + 1 >= P.frames || zf[1] != 0 || !P.zs);
             }
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256, WPS) void xform_kernel(const XformParams P)
             const float2 wlo = *reinterpret_cast<const float2 *>(&lds_win[2 * i]);         // w[2i], w[2i+1]
             const float2 whi = *reinterpret_cast<const float2 *>(&lds_win[254 - 2 * i]);   // w[254-2i], w[255-2i]
             float2 lo, hi;
-            window_pair(ft.f0[j], ft.f1[j], dl[j], wlo, whi, P.bias, lo, hi);
+            window_pair(ft.f0[j], ft.f1[j], dl[j], wlo, whi, MIX && MS ? bias_blk : P.bias, lo, hi);
             if (emit && !S16) {
                 *reinterpret_cast<float2 *>(oblk + 2 * i) = lo;
                 *reinterpret_cast<float2 *>(oblk + 254 - 2 * i) = hi;
@@ -374,6 +378,7 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     P.mix_pending = L.mix_pending;
     P.mix_flags = L.mix_flags;
     P.surr_mask = L.plan.surr_mask;
+    P.nobias_mask = L.plan.nobias_mask;
     {
         int out_fbw = L.plan.n_out;
         if (L.plan.n_out > 0 && L.plan.in_lfe && L.plan.mix[0][0] == 1) {        // output plane 0 is the LFE plane

@@ -123,7 +123,9 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
  * ac3mi_decode_s16_batch / ac3mi_transcode_batch calls whose request mixes surround channels into MONO, STEREO or 3F;
  * ignored otherwise.  Pass NULL, NULL (the default) for a plain linear mix: identical output unless a stream CHANGES its
  * surround mix level to or from "no surround" between two frames, and then different only in the 256 samples per channel
- * that follow the change.  The byte-stream layer and the a52_* drop-in always use it. */
+ * that follow the change - and, at a non-zero bias, in the blocks of such a frame where liba52 forgets to add the bias to the
+ * left and right outputs (2/1, 2/2 to STEREO and 3/1, 3/2 to 3F with different block sizes in one block: downmix.c:530-583).
+ * The byte-stream layer and the a52_* drop-in always use it. */
 int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
 
 /* How ac3mi_decode_batch / ac3mi_decode_s16_batch / ac3mi_transcode_batch spread the work over the GPU (new):

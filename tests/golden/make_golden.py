@@ -77,8 +77,10 @@ def make_ac3tab():
     print("ac3tab.npz", os.path.getsize(os.path.join(OUT, "ac3tab.npz")), {k: v.shape for k, v in d.items()})
 
 
-MIXFLIP = (("a7_st", 7, 2, (1, 1, 2, 2, 0, 0, 2, 1)), ("a7_mono", 7, 1, (0, 2, 2, 1, 2, 0)), ("a7_dolby", 7, 10, (3, 2, 0, 2, 2, 1)),
-           ("a6_st", 6, 2, (1, 2, 2, 0, 2, 1)), ("a5_st", 5, 2, (0, 2, 1, 2, 2, 3)), ("a4_mono", 4, 1, (1, 2, 0, 2, 2, 1)))
+MIXFLIP = (("a7_st", 7, 2, (1, 1, 2, 2, 0, 0, 2, 1), 0.0), ("a7_mono", 7, 1, (0, 2, 2, 1, 2, 0), 0.0), ("a7_dolby", 7, 10, (3, 2, 0, 2, 2, 1), 0.0),
+           ("a6_st", 6, 2, (1, 2, 2, 0, 2, 1), 0.0), ("a5_st", 5, 2, (0, 2, 1, 2, 2, 3), 0.0), ("a4_mono", 4, 1, (1, 2, 0, 2, 2, 1), 0.0),
+           # at bias 384 (what the ACM driver decodes at): 2/x -> stereo and 3/x -> 3F lose the bias in blocks of mixed block sizes
+           ("a6_st_b384", 6, 2, (1, 2, 2, 0, 2, 1), 384.0), ("a7_3f_b384", 7, 3, (2, 2, 1, 2, 2, 0), 384.0), ("a4_st_b384", 4, 2, (2, 2, 2, 3, 2, 2), 384.0))
 
 
 def make_mixflip():
@@ -86,14 +88,15 @@ def make_mixflip():
     from tests import packer
     assert H.have_ref()
     d = {}
-    for tag, acmod, flags, levels in MIXFLIP:
+    for tag, acmod, flags, levels, bias in MIXFLIP:
         fr = packer.make_flip_stream(2600 + acmod + flags, levels, acmod=acmod)
-        pcm, errs, oflags = H.ref_decode(fr, flags, 1.0, 0.0)
+        pcm, errs, oflags = H.ref_decode(fr, flags, 1.0, bias)
         assert errs == 0
         d["frames_" + tag] = fr
         d["pcm_" + tag] = pcm
         d["args_" + tag] = np.array([flags, oflags], np.int32)
         d["levels_" + tag] = np.array(levels, np.int32)
+        d["bias_" + tag] = np.array([bias], np.float32)
     np.savez_compressed(os.path.join(OUT, "mixflip.npz"), **d)
     print("mixflip.npz", os.path.getsize(os.path.join(OUT, "mixflip.npz")))
 

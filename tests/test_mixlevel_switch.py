@@ -17,7 +17,7 @@ import pytest
 from tests import _harness as H
 from tests import packer
 
-TAGS = ["a7_st", "a7_mono", "a7_dolby", "a6_st", "a5_st", "a4_mono"]
+TAGS = ["a7_st", "a7_mono", "a7_dolby", "a6_st", "a5_st", "a4_mono", "a6_st_b384", "a7_3f_b384", "a4_st_b384"]
 
 
 def _bits(a):
@@ -28,7 +28,7 @@ def _bits(a):
 def test_oracle_reproduces_liba52_when_the_surround_level_changes(tag):
     d = np.load(os.path.join(H.GOLDEN, "mixflip.npz"), allow_pickle=False)
     flags, oflags = (int(x) for x in d["args_" + tag])
-    pcm, errs, out = H.orc_decode(d["frames_" + tag], flags, 1.0, 0.0)
+    pcm, errs, out = H.orc_decode(d["frames_" + tag], flags, 1.0, float(d["bias_" + tag][0]))
     assert errs == 0 and out == oflags
     assert np.array_equal(_bits(pcm), _bits(d["pcm_" + tag]))
 
@@ -51,7 +51,7 @@ def test_oracle_matches_liba52_on_fresh_level_changes():
 
 # ---------------------------------------------------------------------------------------------------
 
-def _gpu_decode(engine, frames, acmod, flags, frames_per_call, mix_state):
+def _gpu_decode(engine, frames, acmod, flags, frames_per_call, mix_state, bias=0.0):
     """frames [F][bytes] of one stream -> PCM [F][6][n_out][256], decoded in calls of `frames_per_call` frames"""
     import torch
     pkg = H.pkg()
@@ -59,7 +59,7 @@ def _gpu_decode(engine, frames, acmod, flags, frames_per_call, mix_state):
     stride = (fb + 3) & ~3
     padded = np.zeros((1, F, stride), np.uint8)
     padded[0, :, :fb] = frames
-    desc = pkg.DecodeDesc(flags=flags, level=1.0, bias=0.0, dynrng=1, acmod=acmod, lfeon=0, frame_bytes=fb)
+    desc = pkg.DecodeDesc(flags=flags, level=1.0, bias=bias, dynrng=1, acmod=acmod, lfeon=0, frame_bytes=fb)
     n_out, _ = engine.decode_planes(desc)
     delay = torch.zeros((1, n_out, 128), dtype=torch.float32, device="cuda")
     lfsr = torch.ones((1,), dtype=torch.int16, device="cuda")
@@ -88,10 +88,17 @@ def test_gpu_equals_liba52_when_the_surround_level_changes(engine, tag, frames_p
     flags = int(d["args_" + tag][0])
     acmod = int(tag[1])
     frames, want = d["frames_" + tag], d["pcm_" + tag]
-    got = _gpu_decode(engine, frames, acmod, flags, frames_per_call, mix_state=True)
+    bias = float(d["bias_" + tag][0])
+    got = _gpu_decode(engine, frames, acmod, flags, frames_per_call, mix_state=True, bias=bias)
     want = want.reshape(got.shape)
+    if bias:
+        # liba52 forgets the bias in some blocks of these streams (MixPlan::nobias_mask): make sure the fixture shows it
+        means = want.mean(axis=3)
+        assert (means < 200).any() and (means > 300).any()
     err = got.astype(np.float64) - want
-    scale_rms, scale_max = max(1.0, H.rms(want)), max(1.0, float(np.abs(want).max()))
+    scale_rms, scale_max = max(1.0, H.rms(want - bias)), max(1.0, float(np.abs(want - bias).max()))
+    if bias:
+        scale_rms, scale_max = 40.0 * scale_rms, 40.0 * scale_max       # float32 resolution at 384 (as tests/test_dropin_gpu.py)
     per_block = np.abs(err).max(axis=(2, 3))
     assert H.rms(err) <= 1e-6 * scale_rms and np.abs(err).max() <= 1e-5 * scale_max, (tag, np.argwhere(per_block > 1e-5 * scale_max)[:8].tolist())
 
