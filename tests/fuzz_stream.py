@@ -69,6 +69,60 @@ def main():
     r = -1
     while done < rounds:
         r += 1
+        if r % 3 == 2:
+            # ---- PCM -> AC-3: random channel count / rate / bit rate, random chunks and destination sizes ----
+            nch = int(rng.integers(1, 7))
+            rate = int(rng.choice([48000, 44100, 32000]))
+            kb = int(rng.choice(KBPS))
+            if kb < 32 * nch:
+                continue
+            fb = pkg.EncodeDesc(rate, kb * 1000, nch).frame_bytes()
+            if fb == 0:
+                continue
+            F = int(rng.integers(2, 6))
+            pcm = H.gen_pcm(F, nch, seed=seed0 * 1000 + r, kind=("tones", "noise", "quiet", "music", "bursts", "strobe")[int(rng.integers(0, 6))])
+            chmap = [0, 1, 2, 3, 4, 5, 6, 7]
+            if nch in (3, 5):
+                chmap[1], chmap[2] = 2, 1
+            if nch == 6:
+                chmap[:6] = [0, 2, 1, 4, 5, 3]          # create_channel_map, src/AC3ACM.cpp:1631-1662
+            try:
+                want = H.orc_encode(pcm, nch=nch, bitrate=kb * 1000, freq=rate, chmap=tuple(chmap)).tobytes()
+            except AssertionError:
+                continue
+            rc, st = pool.open(S.pcm_format(nch, rate), S.ac3_format(nch, rate, kb))
+            if rc != 0 or st is None:
+                print("round %d: encode open refused rc %d (%d ch %d Hz %d kbps)" % (r, rc, nch, rate, kb))
+                continue
+            model = M.EncodeModel(channels=nch, frame_bytes=fb)
+            data = pcm.tobytes()
+            out = bytearray()
+            pos = 0
+            first = True
+            ok, note = True, ""
+            for it in range(400):
+                n = int(min(len(data) - pos, rng.integers(0, 20000)))
+                dcap = int(rng.choice([300, 700, 1536, 4096]))
+                src = np.frombuffer(data[pos:pos + n] if n else b"\0", np.uint8).copy()
+                dst = np.zeros(dcap, np.uint8)
+                h = S.StreamHeader(src.ctypes.data, n, 0, dst.ctypes.data, dcap, 0, S.STREAMCONVERTF_START if first else 0)
+                assert st.convert(h) == 0
+                su_du = model.convert(n, dcap, first)
+                if (h.src_used, h.dst_used) != su_du:
+                    ok, note = False, "byte accounting at call %d: %s vs %s" % (it, (h.src_used, h.dst_used), su_du)
+                    break
+                out += dst[:h.dst_used].tobytes()
+                pos += h.src_used
+                first = False
+                if pos == len(data) and len(out) == len(want):
+                    break
+            st.close()
+            if ok and bytes(out) != want:
+                ok, note = False, "%d of %d bytes, %d differing" % (len(out), len(want), sum(a != b for a, b in zip(out, want)))
+            print("round %3d encode %d ch %5d Hz %3d kbps %d frames: %s%s" % (done, nch, rate, kb, F, "ok" if ok else "MISMATCH ", note), flush=True)
+            bad += not ok
+            done += 1
+            continue
         acmod, lfe = int(rng.integers(1, 8)), int(rng.integers(0, 2))
         fscod, fsz = int(rng.integers(0, 3)), int(rng.integers(24, 38))
         F = int(rng.integers(2, 7))
