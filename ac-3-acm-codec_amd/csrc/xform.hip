@@ -420,13 +420,15 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     // (measured on MI355X, 65 536 frames: 4 per CU 0.979 / 0.950 ms, 3 per CU 0.947 / 0.916 ms, 2 per CU 1.082 ms; the bare copy
     // with this addressing shows the same trend, profiles/hbm_calibrate).  AC3MI_XFORM_LDS_PAD overrides (occupancy sweeps).
     static const int lds_pad = getenv("AC3MI_XFORM_LDS_PAD") ? atoi(getenv("AC3MI_XFORM_LDS_PAD")) : 14 * 1024;
+    static const int lds_pad_s16 = getenv("AC3MI_XFORM_LDS_PAD_S16") ? atoi(getenv("AC3MI_XFORM_LDS_PAD_S16")) : 0;
+    static const int lds_pad_mix = getenv("AC3MI_XFORM_LDS_PAD_MIX") ? atoi(getenv("AC3MI_XFORM_LDS_PAD_MIX")) : 0;
     P.pcm16 = L.pcm16;
     if (L.pcm16) {
         int map[6];
         if (s16_channel_map(L.s16_flags, map) != P.n_out || ((uintptr_t)L.pcm16 & 15)) return hipErrorInvalidValue;
         for (int w = 0; w < P.n_out; w++) P.wslot[map[w]] = (int8_t)w;
         if (identity)
-            hipLaunchKernelGGL((xform_kernel<false, 3, true>), dim3(grid), dim3(256), 0, stream, P);
+            hipLaunchKernelGGL((xform_kernel<false, 3, true>), dim3(grid), dim3(256), lds_pad_s16, stream, P);
         else if (mixstate)
             hipLaunchKernelGGL((xform_kernel<true, 2, true, true>), dim3(grid), dim3(256), 0, stream, P);
         else
@@ -438,7 +440,7 @@ hipError_t launch_xform(const DeviceTables &tab, const XformLaunch &L, hipStream
     else if (mixstate)
         hipLaunchKernelGGL((xform_kernel<true, 2, false, true>), dim3(grid), dim3(256), 0, stream, P);
     else        // 167 VGPRs with the planes of an output accumulated one after the other (187 with their loads unrolled): 3 workgroups per CU
-        hipLaunchKernelGGL((xform_kernel<true, 3>), dim3(grid), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((xform_kernel<true, 3>), dim3(grid), dim3(256), lds_pad_mix, stream, P);
     return hipGetLastError();
 }
 
