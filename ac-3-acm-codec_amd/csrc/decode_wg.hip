@@ -39,7 +39,6 @@ namespace ac3mi {
 
 namespace wg {
 
-constexpr int N_WAVES = 8;
 #ifndef WG_LB
 #define WG_LB 4                             // waves per SIMD the register budget is set for (512-thread blocks: 2 per block):
                                             // 128 VGPRs, two workgroups per CU, practically no spills.  6 (80 VGPRs, three per CU)
