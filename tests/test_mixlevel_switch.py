@@ -125,13 +125,24 @@ def test_plain_linear_mix_differs_only_right_after_a_level_change(engine, tag):
 
 
 @pytest.mark.gpu
-def test_gpu_equals_oracle_on_fresh_level_changes_many_streams(engine):
+def test_mix_state_follows_the_streams_through_workspace_tiles(engine):
+    """ac3mi_set_tile_frames small enough that a call works through its streams in tiles of whole streams: the mix state
+    arrays move along like the overlap tails."""
+    engine.set_tile_frames(4)
+    try:
+        test_gpu_equals_oracle_on_fresh_level_changes_many_streams(engine, acmods=(7,), per_calls=(2, 6))
+    finally:
+        engine.set_tile_frames(131072)
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_on_fresh_level_changes_many_streams(engine, acmods=(4, 5, 6, 7), per_calls=(1, 2, 6)):
     """Several streams per call with different level sequences, with and without an LFE channel, all three outputs the
     quirk applies to, one / two / all frames per call - against the oracle, which the tests above pin to liba52."""
     import torch
     pkg = H.pkg()
     rng = np.random.default_rng(5)
-    for acmod in (4, 5, 6, 7):
+    for acmod in acmods:
         for lfe in (0, 1):
             S, F = 5, 6
             seqs = [[int(x) for x in rng.choice([0, 1, 2, 2, 3], F)] for _ in range(S)]
@@ -146,7 +157,7 @@ def test_gpu_equals_oracle_on_fresh_level_changes_many_streams(engine):
                 want = np.stack([H.orc_decode(streams[s], req, 1.0, 0.0)[0] for s in range(S)])
                 desc = pkg.DecodeDesc(flags=req, level=1.0, bias=0.0, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
                 n_out, _ = engine.decode_planes(desc)
-                for per_call in (1, 2, F):
+                for per_call in per_calls:
                     delay = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
                     lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
                     pend = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
