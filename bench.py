@@ -238,7 +238,7 @@ def ac3_crc_ok(frames):
     return int(np.count_nonzero(bad1 | (crc != 0)))
 
 
-def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=5, checks=True):
+def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=True):
     """Whole-path numbers for the other BASELINE configs on the same batch size (frames resident in HBM):
     configs[2] encode (s16 PCM -> frames), bitstream decode (frames -> float PCM, both kernels) and
     decode -> s16 -> re-encode (configs[4]'s per-GPU transcode step).  Each: frames/s of this rank's shard
@@ -535,7 +535,7 @@ def importlib_pkg():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
