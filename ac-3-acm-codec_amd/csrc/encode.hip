@@ -875,6 +875,12 @@ __device__ unsigned long long g_pack_cycles[8];
 #define PK_END() do { } while (0)
 #endif
 
+// offsets costed per sweep of the SNR-offset search (two per packed 16-bit pipeline).  4 saves a sweep now and then but costs
+// registers and reductions: 6.01 - 6.04 against 5.92 ms per 65 536 one-frame streams, 1 % ahead on long streams; 3 stays
+#ifndef ENC_NC
+#define ENC_NC 3
+#endif
+
 #ifndef ENC_PACK_LB
 #define ENC_PACK_LB 4            // wavefronts per SIMD the packer's register budget is set for (128 VGPRs; at 5 the branch-free mantissa passes spill: 6.26 vs 6.09 ms per 65 536 frames)
 #endif
@@ -1019,9 +1025,11 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             if (!loaded) load_frame();
             PK_COUNT(4);
             const int budget = 16 * fs - frame_bits;
-            uint32_t acc[6][3];
+            uint32_t acc[6][ENC_NC];
 #pragma unroll
-            for (int B = 0; B < 6; B++) acc[B][0] = acc[B][1] = acc[B][2] = 0;
+            for (int B = 0; B < 6; B++)
+#pragma unroll
+                for (int c = 0; c < ENC_NC; c++) acc[B][c] = 0;
             {
                 // one run-start row per step: four bins per lane from one dword (HBM/L2), the next row's dword in flight
                 // (the exponent dwords of the next three rows are in flight while one is costed)
@@ -1033,6 +1041,7 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 int r1 = row_of(t1, r), r2 = row_of(t2, r1);
                 uint32_t ev = fetch(r), ev1 = fetch(r1), ev2 = fetch(r2);
                 const pk2 so01 = {(short)so[0], (short)so[1]};
+                const pk2 so23 = {(short)so[2], (short)so[ENC_NC - 1]};
 #pragma unroll 1
                 while (todo) {
                     todo &= todo - 1;
@@ -1044,7 +1053,9 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                     const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
                     const int b1 = __builtin_ctz(starts >> (b0 + 1)) + b0 + 1;
                     const int16_t *Mr = &L.mask[r][0];
-                    uint32_t sum[3] = {0, 0, 0};
+                    uint32_t sum[ENC_NC];
+#pragma unroll
+                    for (int c = 0; c < ENC_NC; c++) sum[c] = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int e = (ev >> (8 * j)) & 0xff, m = Mr[(bandoff >> (8 * j)) & 0xff];
@@ -1052,13 +1063,18 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                         const pk2 a01 = lut_index2(d4, m, so01);
                         sum[0] += L.bitlut[(uint16_t)a01.x >> 2];
                         sum[1] += L.bitlut[(uint16_t)a01.y >> 2];
-                        sum[2] += L.bitlut[lut_index(d4, m, so[2])];
+                        if (ENC_NC == 3) sum[2] += L.bitlut[lut_index(d4, m, so[2])];
+                        else {
+                            const pk2 a23 = lut_index2(d4, m, so23);
+                            sum[2] += L.bitlut[(uint16_t)a23.x >> 2];
+                            sum[ENC_NC - 1] += L.bitlut[(uint16_t)a23.y >> 2];
+                        }
                     }
 #pragma unroll
                     for (int B = 0; B < 6; B++) {
                         const uint32_t in_run = (B >= b0 && B < b1) ? 1u : 0u;       // wave-uniform
 #pragma unroll
-                        for (int k = 0; k < 3; k++)         // (written out: the compiler turns a multiply by 0/1 back into select + add)
+                        for (int k = 0; k < ENC_NC; k++)    // (written out: the compiler turns a multiply by 0/1 back into select + add)
                             asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[B][k]) : "v"(sum[k]), "s"(in_run));
                     }
                     r = r1; r1 = r2; r2 = r3;
@@ -1066,11 +1082,13 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                     t2 = t3;
                 }
             }
-            int total[3] = {0, 0, 0};
+            int total[ENC_NC];
+#pragma unroll
+            for (int c = 0; c < ENC_NC; c++) total[c] = 0;
 #pragma unroll
             for (int B = 0; B < 6; B++) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
+                for (int c = 0; c < ENC_NC; c++) {
                     const uint32_t sa = wave_sum_u32((acc[B][c] & 0x1ffu) | (((acc[B][c] >> 9) & 31u) << 16));
                     const uint32_t sb = wave_sum_u32(((acc[B][c] >> 14) & 31u) | (((acc[B][c] >> 19) & 31u) << 16));
                     const int bits = sa & 0xffff, n1 = sa >> 16, n2 = sb & 0xffff, n4 = sb >> 16;
@@ -1101,17 +1119,17 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             if (!more) break;
             // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
             // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
-            int so[3], cand_c[3], cand_f[3], n_cand = 0;
+            int so[ENC_NC], cand_c[ENC_NC], cand_f[ENC_NC], n_cand = 0;
             {
                 SnrSearch ahead = ss;
-                while (n_cand < 3 && ahead.next(cc, ff)) {
+                while (n_cand < ENC_NC && ahead.next(cc, ff)) {
                     bool fits;
                     if (!lookup(cc, ff, fits)) {
                         bool dup = false;
                         for (int i = 0; i < n_cand; i++) dup = dup || (cand_c[i] == cc && cand_f[i] == ff);
                         if (dup) break;
                         const int v = (((cc - 15) << 4) + ff) << 2;
-                        if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                        if (n_cand == 0) for (int q = 0; q < ENC_NC; q++) so[q] = v;
                         cand_c[n_cand] = cc; cand_f[n_cand] = ff;
                         so[n_cand++] = v;
                         fits = ahead.phase == 0 ? !went_down : ahead.phase == 1 ? went_up : true;
@@ -1127,11 +1145,11 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             // answered unless the fit is not monotone around here or the level jumps between frames.
             const int C = ss.failed ? 0 : ss.csnr;
             for (;;) {
-                int so[3], cand_c[3], cand_f[3], n_cand = 0;
-                for (int c = C - 7 < 0 ? 0 : C - 7; c <= (C + 8 > 63 ? 63 : C + 8) && n_cand < 3; c++) {
+                int so[ENC_NC], cand_c[ENC_NC], cand_f[ENC_NC], n_cand = 0;
+                for (int c = C - 7 < 0 ? 0 : C - 7; c <= (C + 8 > 63 ? 63 : C + 8) && n_cand < ENC_NC; c++) {
                     if ((known_c >> c) & 1) continue;
                     const int v = ((c - 15) << 4) << 2;
-                    if (n_cand == 0) so[0] = so[1] = so[2] = v;
+                    if (n_cand == 0) for (int q = 0; q < ENC_NC; q++) so[q] = v;
                     cand_c[n_cand] = c; cand_f[n_cand] = 0;
                     so[n_cand++] = v;
                 }
