@@ -115,6 +115,12 @@ struct DecodeLaunch {
     int frame_parallel;
     uint32_t *frame_draws;  // [S][F] workspace
     uint16_t *frame_lfsr;   // [S][F] workspace
+    // split front end (parse kernel + one wavefront per audio block): workspaces, all or none
+    int split = 0;
+    void *ws_desc = nullptr;        // [S][F][6] BlkDesc (80 bytes)
+    uint8_t *ws_rows = nullptr;     // [S][F][6][7][512]
+    float *ws_cplco = nullptr;      // [S][F][6][90]
+    uint32_t *ws_fpos = nullptr;    // [S][F]
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 // decode_wg.hip: one workgroup per stream; X == nullptr: coefficient planes (+ taps) to HBM as launch_decode does;
@@ -180,8 +186,10 @@ struct ac3mi_ctx {
     int32_t *mix_flags;
     bool no_overlap;        // AC3MI_NO_OVERLAP in the environment: no chunk pipelines (clean per-kernel profiles)
     long long tile_frames;  // workspace bound: batches above this many frames go through in tiles of whole streams (0 = never)
-    int decode_mode;        // 0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame
+    int decode_mode;        // ac3mi_set_decode_mode
     uint32_t *ws_draws;     // [S][F] draw counts + [S][F] u16 frame-start LFSR states (decode, frame-parallel)
     size_t ws_draws_bytes;
+    void *ws_split;         // descriptors, rows, coupling coordinates, generator positions between the split front end's kernels
+    size_t ws_split_bytes;
     std::string err;
 };

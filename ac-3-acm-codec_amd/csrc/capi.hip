@@ -454,12 +454,14 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->decode_mode = 0;
     if (const char *e = getenv("AC3MI_DECODE_MODE")) {          // test aid: default front-end variant (ac3mi_set_decode_mode)
         const int m = atoi(e);
-        if (m >= 0 && m <= 3) ctx->decode_mode = m;
+        if (m >= 0 && m <= 5) ctx->decode_mode = m;
     }
     ctx->tile_frames = 131072;
     ctx->no_overlap = getenv("AC3MI_NO_OVERLAP") != nullptr;     // profiling aid: one chunk, one stream, kernels back to back
     ctx->ws_draws = nullptr;
     ctx->ws_draws_bytes = 0;
+    ctx->ws_split = nullptr;
+    ctx->ws_split_bytes = 0;
     ctx->ws_coef = nullptr;
     ctx->ws_blksw = nullptr;
     ctx->mix_pending = nullptr;
@@ -489,6 +491,7 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->ws_enc);
     (void)hipFree(ctx->ws_tc);
     (void)hipFree(ctx->ws_draws);
+    (void)hipFree(ctx->ws_split);
     (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -661,7 +664,7 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags)
 
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 3) return AC3MI_ERR_ARG;
+    if (!ctx || mode < 0 || mode > 5) return AC3MI_ERR_ARG;
     ctx->decode_mode = mode;
     return AC3MI_OK;
 }
@@ -687,8 +690,44 @@ static int tile_streams(const ac3mi_ctx *ctx, int n_streams, int frames_per_stre
 static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
     if (frames_per_stream < 2) return false;
-    if (ctx->decode_mode) return ctx->decode_mode == 2;
+    if (ctx->decode_mode) return ctx->decode_mode == 2 || ctx->decode_mode == 5;
     return n_streams < 5120;
+}
+
+// split front end (parse kernel, then one wavefront per audio block: decode.hip MODE 4 / 5 + mant_kernel)?  auto: yes;
+// modes 1 / 2 force the one-kernel front ends, 4 / 5 the split one per stream / per frame.
+static bool use_split(const ac3mi_ctx *ctx)
+{
+    return ctx->decode_mode == 0 || ctx->decode_mode >= 4;
+}
+
+// workspace of the split front end for nfr frames: descriptors, generator positions, coupling coordinates, row sets
+struct SplitWs { void *desc; uint32_t *fpos; float *cplco; uint8_t *rows; };
+static size_t split_bytes(size_t nfr) { return nfr * (6 * 80 + 16 + 6 * 90 * 4 + 6 * 7 * 512) + 256; }
+static SplitWs split_ws(const ac3mi_ctx *ctx, size_t nfr, size_t f0)
+{
+    SplitWs w;
+    uint8_t *p = (uint8_t *)ctx->ws_split;
+    w.desc = p + f0 * 6 * 80;
+    p += nfr * 6 * 80;
+    w.fpos = (uint32_t *)p + f0;
+    p += nfr * 16;
+    w.cplco = (float *)p + f0 * 6 * 90;
+    p += nfr * 6 * 90 * 4;
+    w.rows = p + f0 * 6 * 7 * 512;
+    return w;
+}
+static int ensure_split(ac3mi_ctx *ctx, size_t nfr)
+{
+    const size_t need = split_bytes(nfr);
+    if (need <= ctx->ws_split_bytes) return AC3MI_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->ws_split);
+    ctx->ws_split = nullptr;
+    ctx->ws_split_bytes = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->ws_split, need));
+    ctx->ws_split_bytes = need;
+    return AC3MI_OK;
 }
 
 // one workgroup per stream (decode_wg.hip)?  Its eight wavefronts cut the latency of a frame to a third (64 - 256 one-frame
@@ -882,6 +921,8 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
 
     const bool fp = !wgk && use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
+    const bool split = !wgk && use_split(ctx);
+    if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
     // One workgroup per stream, one wavefront per channel, the transform fused in when every
     // coded plane is an output plane (decode_wg.hip) - no coefficient planes in HBM.  Stage taps and mixing outputs
     // take the same front end with the planes written out, then the transform kernel.
@@ -963,6 +1004,11 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.frame_parallel = fp ? 1 : 0;
         D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
         D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;
+        if (split) {
+            const SplitWs w = split_ws(ctx, nfr, f0);
+            D.split = 1;
+            D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
+        }
         HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
 
         hipStream_t xs = ctx->stream;
@@ -1247,6 +1293,8 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
     const bool fp = !fused && use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
+    const bool split = !fused && use_split(ctx);
+    if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
     const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
@@ -1276,6 +1324,11 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         D.frame_parallel = fp ? 1 : 0;
         D.frame_draws = fp ? ctx->ws_draws + f0 : nullptr;
         D.frame_lfsr = fp ? (uint16_t *)(ctx->ws_draws + nfr) + f0 : nullptr;
+        if (split) {
+            const SplitWs w = split_ws(ctx, nfr, f0);
+            D.split = 1;
+            D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
+        }
         if (fused) {
             XformLaunch Y = X;
             Y.coef = nullptr;

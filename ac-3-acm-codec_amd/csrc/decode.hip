@@ -39,6 +39,13 @@ namespace ac3mi {
 #ifndef DEC_LB0
 #define DEC_LB0 4
 #endif
+// MODE 4 (one wavefront per stream) / MODE 5 + lfsr_prefix_kernel (one per frame): the parse half of the split front
+// end - side information, exponents, bit allocation; the mantissas of a block are only COUNTED, from per-row totals, and
+// mant_kernel (one wavefront per audio block, a workgroup per frame) unpacks them from the block descriptors and rows
+// this kernel leaves in the workspace (BlkDesc, decode_common.h).
+#ifndef DEC_LBP
+#define DEC_LBP 5
+#endif
 // Measurement aid (make EXTRA=-DDEC_STAMPS, a separate library): lane 0 of every wavefront adds the s_memtime cycles of
 // a frame's sections to g_dec_cycles: 0 staging + header, 1 side information, 2 exponents, 3 bit-allocation parameters +
 // bit allocation, 4 mantissas (+ coupling, rematrix, stores), 5 the rest.  ac3mi_debug_dec_cycles reads them.
@@ -56,15 +63,17 @@ __device__ unsigned long long g_dec_cycles[8];
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kernel(const DecodeParams P)
+__global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kernel(const DecodeParams P)
 {
+    constexpr bool SERIAL = MODE == 0 || MODE == 4;         // one wavefront per stream, frames in order
+    constexpr bool PARSE = MODE >= 4;                       // no mantissa values: block descriptors + rows for mant_kernel
     __shared__ DecLDS L;
     extern __shared__ uint32_t frw[];
     const FrameBits FB{frw, (uint32_t)((P.frame_bytes + 3) >> 2) + 2u};
     const int lane = threadIdx.x;
-    const int s = MODE == 0 ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)P.frames_per_stream);
-    const int f_first = MODE == 0 ? 0 : (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream);
-    const int f_end = MODE == 0 ? P.frames_per_stream : f_first + 1;
+    const int s = SERIAL ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)P.frames_per_stream);
+    const int f_first = SERIAL ? 0 : (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream);
+    const int f_end = SERIAL ? P.frames_per_stream : f_first + 1;
     if (s >= P.n_streams) return;
 
     // ---- constant tables into LDS ----
@@ -94,10 +103,14 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
     st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
     DK_DECL();
-    st.lfsr = MODE == 0 ? (uint32_t)P.lfsr_state[sslot]
+    st.lfsr = (MODE == 0 || MODE == 4) ? (uint32_t)P.lfsr_state[sslot]
             : MODE == 2 ? (uint32_t)P.frame_lfsr[(size_t)s * P.frames_per_stream + f_first] : 1u;
     int hth_fscod = -1;
     uint32_t frame_draws = 0;
+    // MODE 4: the generator's position along its cycle instead of its state (k draws = k positions)
+    const bool pos_live = st.lfsr != 0;
+    uint32_t lfsr_pos = MODE == 4 ? (uint32_t)P.lfsr_idx[st.lfsr] : 0u;
+    if (PARSE && lane < 7) L.tot[lane][2] = 0;
 
     for (int f = f_first; f < f_end; f++) {
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
@@ -107,6 +120,11 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
         // block 0 takes exponents, coupling or bit-allocation parameters the frame did not send (not a conforming frame):
         // what it reuses is whatever the variant at hand has carried so far, so results may depend on the batch shape
         bool reuse0 = false;
+        // parse modes: rows of this frame's row sets not written yet (bit = slot), and the block that holds each slot's
+        // current row (4 bits per slot)
+        int dirty_exp = 0x7f, dirty_bap = 0x7f;
+        uint32_t rv_exp = 0, rv_bap = 0;
+        if (MODE == 4) frame_draws = 0;
 
         DK_T0();
         // ---- stage the frame: byte-swapped dwords, zero padded ----
@@ -196,6 +214,8 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
             const int in_lfe = P.lfeon ? 1 : 0;
             int err = frame_dead ? 1 : 0;
             int blkswm = 0, dithmask = 0;
+            BlkDesc bd;
+            bd.flags = 1u;
             float gain[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             const int nf = st.nf;
 
@@ -312,6 +332,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                 }
 
                 DK_LAP(2);
+                dirty_exp |= redo;                                          // (bits: 0..4 fbw, 5 lfe, 6 coupling channel)
                 // ---- bit-allocation parameters: parse.c:738-772 ----
                 if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
                 else if (blk == 0) reuse0 = true;
@@ -366,6 +387,8 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
 #pragma unroll
                     for (int i = 0; i < 5; i++)
                         if (i < nf && (st.cbai[i] >> 3)) allzero = false;
+                    dirty_bap |= allzero ? 0x7f : redo;
+                    if (PARSE && lane < 7 && (allzero || ((redo >> lane) & 1))) L.tot[lane][2] = 0;
                     if (allzero) {
                         for (int i = lane; i < ROWS; i += 64) L.bap[i] = 0;
                     } else {
@@ -441,164 +464,101 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
                 // ---- gains: parse.c:810-811 ----
                 a52_downmix_coeff_hd(gain, st.acmod, st.output, st.dynrng, st.clev, st.slev);
 
-                // ---- mantissas: the segments of the block in bitstream order (parse.c:813-879: channel 0, the coupling
-                //      channel right after the first coupled channel, ..., LFE last), one step of four bins per lane each
-                //      (mant_first_half / mant_value, decode_common.h).  Ranks of the grouped codes, bit offsets and dither
-                //      draw indices run on from segment to segment; planes go straight to HBM, 16 bytes per lane. ----
-                if (st.chincpl && lane < 18) {                              // sub-band -> band (parse.c:448-456)
+                // ---- mantissas: the segments of the block in bitstream order (mant_block, decode_common.h) ----
+                if (!PARSE && st.chincpl && lane < 18) {                    // sub-band -> band (parse.c:448-456)
                     const uint32_t below = st.cplbndstrc & ((1u << lane) - 1u);
                     L.cplbnd[lane] = (uint8_t)(lane - __popc(below));
                 }
-                const int ncpl_dith = __popc(st.chincpl & dithmask);
-                const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
-                const bool lfsr_live = st.lfsr != 0;
-                const int remat_end = st.endmant[0] < st.endmant[1] ? st.endmant[0] : st.endmant[1];
-                // Only a damaged frame can put rematrixed bins inside the coupling range (a coupled channel that reuses its
-                // exponents keeps the previous block's end): liba52 rematrixes the planes as they stand after coupling and
-                // zeroing (parse.c:837-865), so that case runs as a pass of its own after the segments.
-                const bool remat_late = st.acmod == 2 && st.rematflg != 0 && st.chincpl != 0 && remat_end > st.cplstrtmant;
-                const int cplfirst = st.chincpl ? __builtin_ctz(st.chincpl) : 99;
-                const int nseg = nf + (st.chincpl ? 1 : 0) + (st.lfeon ? 1 : 0);
                 SegBase sb;
                 sb.bit = rd.pos;
                 sb.r3 = sb.r5 = sb.r11 = sb.draw = 0;
-                for (int k = 0; k < nseg; k++) {
-                    // segment k -> slot (0..4 fbw, 5 lfe, 6 coupling channel)
-                    int slot;
-                    if (st.chincpl) slot = k <= cplfirst ? k : k == cplfirst + 1 ? 6 : k - 1 < nf ? k - 1 : 5;
-                    else slot = k < nf ? k : 5;
-                    int start = 0, end, draws = 0;
-                    float g = 0.f;
-                    if (slot < 5) {
-                        end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2] : slot == 3 ? st.endmant[3] : st.endmant[4];
-                        g = slot == 0 ? gain[0] : slot == 1 ? gain[1] : slot == 2 ? gain[2] : slot == 3 ? gain[3] : gain[4];
-                        draws = (dithmask >> slot) & 1;
-                    } else if (slot == 5) {
-                        end = 7;
-                        g = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
-                    } else {
-                        start = st.cplstrtmant;
-                        end = st.cplendmant;
-                        draws = ncpl_dith;
-                    }
-                    sb.mult = draws;
-                    BinRegs R;
-                    const SegTotals T = mant_first_half<GRING, GRING - 1, MODE == 1>(L.exp + row_off(slot), L.bap + row_off(slot), L.desc, L.gcode, frw,
-                                                                                    FB.last, start, end, slot == 5 ? LFE_ROW / 4 : 64, sb, R, lane);
-                    sb.bit += T.bits;
-                    sb.r3 += T.n3;
-                    sb.r5 += T.n5;
-                    sb.r11 += T.n11;
-                    sb.draw += T.draws;
-                    if (MODE == 1) continue;                         // counting pass: ranks, bit offsets and draw counts only
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (slot < 6) {
-                        float out[4];
-                        int cd = R.cd;
-                        const bool dith = draws != 0 && lfsr_live;
+                if constexpr (!PARSE) {
+                    MantBlk B;
+                    B.nf = nf; B.lfeon = st.lfeon; B.acmod = st.acmod; B.in_lfe = in_lfe;
+                    B.chincpl = st.chincpl; B.dithmask = dithmask; B.rematflg = st.rematflg;
+                    B.cplstrtmant = st.cplstrtmant; B.cplendmant = st.cplendmant;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int bin = 4 * lane + j;
-                            const bool zero = bin < end && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
-                            const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
-                            float q = mant_value<GRING, GRING - 1>(R, j, L.desc, L.gcode, P.tab->qtab);
-                            if (dith && __any(zero)) {                // wave-uniform: no table access when no lane draws
-                                const float dv = (float)dither_value(P, lfsr_i0, cd);
-                                q = zero ? dv : q;
-                            }
-                            cd += (zero && draws) ? 1 : 0;
-                            out[j] = q * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
+                    for (int i = 0; i < 5; i++) { B.endmant[i] = st.endmant[i]; B.gain[i] = gain[i]; }
+                    B.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+                    const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
+                    const bool lfsr_live = st.lfsr != 0;
+                    mant_block<MODE == 1>(B, [&](int slot) { return (const uint8_t *)L.exp + row_off(slot); },
+                                          [&](int slot) { return (const int8_t *)L.bap + row_off(slot); },
+                                          [&](int c, int bnd) { return L.cplco[c][bnd]; }, L.cplbnd, L.desc, L.gcode, frw, FB.last,
+                                          P.tab->qtab, P.lfsr_seq, lfsr_i0, lfsr_live, cblk, sb, lane);
+                    // advance the dither generator past this block's draws
+                    if (MODE != 1 && lfsr_live && sb.draw) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)sb.draw) % 65535u];
+                } else {
+                    // parse only: the totals of every segment's row (cached per slot while row and range stay) give the bits and
+                    // the dither draws of the block; rows that changed go to the workspace; the descriptor names them
+                    const int cplfirst = st.chincpl ? __builtin_ctz(st.chincpl) : 99;
+                    const int nseg = nf + (st.chincpl ? 1 : 0) + (st.lfeon ? 1 : 0);
+                    const int ncpl_dith = __popc(st.chincpl & dithmask);
+                    uint8_t *rowset = P.rows + (fidx * 6 + blk) * (size_t)ROWSET;
+                    for (int k = 0; k < nseg; k++) {
+                        const int slot = seg_slot(k, nf, st.chincpl, cplfirst);
+                        int start = 0, end, mult = 0;
+                        if (slot < 5) {
+                            end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2] : slot == 3 ? st.endmant[3] : st.endmant[4];
+                            mult = (dithmask >> slot) & 1;
+                        } else if (slot == 5) end = 7;
+                        else { start = st.cplstrtmant; end = st.cplendmant; mult = ncpl_dith; }
+                        const int lanes4 = slot == 5 ? LFE_ROW / 4 : 64;
+                        const uint32_t key = 0x80000000u | (uint32_t)start | ((uint32_t)end << 10);
+                        RowTotals T;
+                        if (rfl(L.tot[slot][2]) == key) { T.a = rfl(L.tot[slot][0]); T.b = rfl(L.tot[slot][1]); }
+                        else {
+                            T = row_totals(L.bap + row_off(slot), start, end, lanes4, lane);
+                            if (lane == 0) { L.tot[slot][0] = T.a; L.tot[slot][1] = T.b; L.tot[slot][2] = key; }
                         }
-                        float *plane = cblk + (slot == 5 ? 0 : slot + in_lfe) * 256;
-                        if (slot == 1 && st.acmod == 2 && st.rematflg != 0 && !remat_late) {
-                            // rematrix: parse.c:837-865.  Channel 0's bins were stored by this same lane.
-                            float4 a4 = *reinterpret_cast<const float4 *>(plane - 256 + 4 * lane);
-                            float a[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int bin = 4 * lane + j;
-                                const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
-                                // (liba52's loop is a do-while, parse.c:846-862: with the first band's flag set it rematrixes bin 13
-                                // even when the channels end at or below it - a damaged frame whose block 0 reuses exponents)
-                                if (bin >= 13 && (bin < remat_end || (bin == 13 && remat_end <= 13)) && ((st.rematflg >> band) & 1)) {
-                                    const float x = a[j], v = out[j];
-                                    a[j] = x + v;
-                                    out[j] = x - v;
-                                }
-                            }
-                            *reinterpret_cast<float4 *>(plane - 256 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+                        const int n3 = (int)((T.a >> 13) & 511u), n5 = (int)(T.a >> 22), n11 = (int)(T.b & 511u), nz = (int)(T.b >> 9);
+                        // a grouped code takes its bits where the member of rank 0 mod 3 (mod 2) stands
+                        const int o3 = (sb.r3 + n3 + 2) / 3 - (sb.r3 + 2) / 3, o5 = (sb.r5 + n5 + 2) / 3 - (sb.r5 + 2) / 3;
+                        const int o11 = ((sb.r11 + n11 + 1) >> 1) - ((sb.r11 + 1) >> 1);
+                        sb.bit += (T.a & 0x1fffu) + 5u * (uint32_t)o3 + 7u * (uint32_t)(o5 + o11);
+                        sb.r3 += n3; sb.r5 += n5; sb.r11 += n11;
+                        sb.draw += nz * mult;
+                        if ((dirty_exp >> slot) & 1) {
+                            if (lane < lanes4) *reinterpret_cast<uint32_t *>(rowset + slot * 512 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.exp + row_off(slot) + 4 * lane);
+                            dirty_exp &= ~(1 << slot);
+                            rv_exp = (rv_exp & ~(7u << (4 * slot))) | ((uint32_t)blk << (4 * slot));
                         }
-                        if (slot < 5 && ((st.chincpl >> slot) & 1)) {
-                            // a coupled channel: its own bins, zeros up to the coupling range (a damaged frame can leave a gap
-                            // there: liba52 then keeps the previous block's PCM, its buffer being transformed in place; here
-                            // zeros) and from the END OF THE COUPLING RANGE on - also where a damaged frame left the channel's own
-                            // end (it keeps the previous block's when the exponents are reused) beyond it: liba52 zeroes from
-                            // cplendmant (parse.c:826-834).  The coupling channel's share in between is written by that segment,
-                            // which comes after the first coupled channel and before the others: as in liba52, a later coupled
-                            // channel's own bins inside the range win over the coupling channel's, the first one's lose.
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int bin = 4 * lane + j;
-                                if (bin < end || bin < st.cplstrtmant || bin >= st.cplendmant) plane[bin] = bin >= st.cplendmant ? 0.f : out[j];
-                            }
-                        } else {
-                            *reinterpret_cast<float4 *>(plane + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
-                        }
-                    } else {
-                        // coupling channel: parse.c:435-556
-                        int cd = R.cd;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int bin = 4 * lane + j;
-                            const bool in = bin >= start && bin < end;
-                            const bool zero = in && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
-                            const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
-                            const float m = mant_value<GRING, GRING - 1>(R, j, L.desc, L.gcode, P.tab->qtab) * sf_of(e);
-                            const int bnd = L.cplbnd[in ? (bin - start) / 12 : 0];
-                            int cdc = cd;
-                            for (int c = 0; c < nf; c++) {
-                                if (!((st.chincpl >> c) & 1)) continue;
-                                const float gc = c == 0 ? gain[0] : c == 1 ? gain[1] : c == 2 ? gain[2] : c == 3 ? gain[3] : gain[4];
-                                const float co = L.cplco[c][bnd] * gc;
-                                float v = m * co;
-                                if (zero) {
-                                    v = 0.f;
-                                    if ((dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_value(P, lfsr_i0, cdc) : 0); cdc++; }
-                                }
-                                if (in) cblk[(c + in_lfe) * 256 + bin] = v;
-                            }
-                            cd += zero ? draws : 0;
+                        if ((dirty_bap >> slot) & 1) {
+                            if (lane < lanes4) *reinterpret_cast<uint32_t *>(rowset + slot * 512 + 256 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.bap + row_off(slot) + 4 * lane);
+                            dirty_bap &= ~(1 << slot);
+                            rv_bap = (rv_bap & ~(7u << (4 * slot))) | ((uint32_t)blk << (4 * slot));
                         }
                     }
-                }
-                if (MODE != 1 && remat_late) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    volatile float *p0 = cblk + (size_t)in_lfe * 256, *p1 = p0 + 256;
-                    for (int bin = 13 + lane; bin < remat_end; bin += 64) {
-                        const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
-                        if ((st.rematflg >> band) & 1) {
-                            const float a = p0[bin], v = p1[bin];
-                            p0[bin] = a + v;
-                            p1[bin] = a - v;
-                        }
+                    if (st.chincpl) {
+                        float *cc = P.cplco + (fidx * 6 + blk) * 90;
+                        cc[lane] = (&L.cplco[0][0])[lane];
+                        if (lane < 26) cc[64 + lane] = (&L.cplco[0][0])[64 + lane];
                     }
+                    bd.bitpos = rd.pos;
+                    bd.draw_off = frame_draws;
+                    bd.flags = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg << 24);
+                    bd.cplbndstrc = st.cplbndstrc;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) { bd.endmant[i] = (uint16_t)st.endmant[i]; bd.gain[i] = gain[i]; }
+                    bd.cplstrt = (uint16_t)st.cplstrtmant;
+                    bd.cplend = (uint16_t)st.cplendmant;
+                    bd.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { bd.rv_exp[i] = (uint8_t)((rv_exp >> (4 * i)) & 7u); bd.rv_bap[i] = (uint8_t)((rv_bap >> (4 * i)) & 7u); }
                 }
                 rd.pos = sb.bit;
-                const int nd_total = sb.draw;
-                frame_draws += (uint32_t)nd_total;
-                // advance the dither generator past this block's draws
-                if (MODE != 1 && lfsr_live && nd_total) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)nd_total) % 65535u];
+                frame_draws += (uint32_t)sb.draw;
             }
 
             DK_LAP(4);
             // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
+            if constexpr (PARSE) {
+                if (err) bd.flags = 1u;
+                if (lane == 0) P.desc[fidx * 6 + blk] = bd;
+            }
             if (MODE != 1) {
-                if (err)
+                if (err && !PARSE)
                     for (int c = 0; c < P.n_in; c++)
                         *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (P.blksw && lane < P.nfchans)
@@ -610,16 +570,23 @@ __global__ __launch_bounds__(64, MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kerne
         DK_LAP(5);
         if (MODE != 1 && lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
         if (MODE != 1 && lane == 0 && P.zs) P.zs[fidx] = (uint8_t)((status & 0x100u) ? 0 : surround_level_is_zero(st.acmod, st.output, st.slev));
-        if (MODE == 1 && lane == 0) P.frame_draws[fidx] = frame_draws;
+        if ((MODE == 1 || MODE == 5) && lane == 0) P.frame_draws[fidx] = frame_draws;
+        if (MODE == 4) {
+            if (lane == 0) P.frame_pos[fidx] = pos_live ? lfsr_pos : 0xffffffffu;
+            lfsr_pos = (lfsr_pos + frame_draws) % 65535u;
+        }
     }
     if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
+    if (MODE == 4 && lane == 0 && pos_live) P.lfsr_state[sslot] = P.lfsr_seq[lfsr_pos];
     DK_END();
     if (MODE == 2 && lane == 0 && f_end == P.frames_per_stream) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
 }
 
 // LFSR state at the start of every frame: one thread per stream walks its frames' draw counts (the generator is
 // GF(2)-linear with period 65535: k draws = k positions along the cycle; state 0 is a fixed point).
-__global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, const uint16_t *lfsr_state, const int32_t *slot,
+// frame_pos (split front end): the position along the cycle instead of the state (0xffffffff: state 0), and the stream's
+// final state written back here (MODE 2 does that itself).
+__global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, uint32_t *frame_pos, uint16_t *lfsr_state, const int32_t *slot,
                                    const uint16_t *seq, const uint16_t *idx, int n_streams, int frames)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,10 +594,107 @@ __global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, 
     uint32_t state = lfsr_state[slot ? slot[s] : s];
     uint32_t pos = idx[state];
     for (int f = 0; f < frames; f++) {
-        frame_lfsr[(size_t)s * frames + f] = (uint16_t)state;
+        if (frame_pos) frame_pos[(size_t)s * frames + f] = state ? pos : 0xffffffffu;
+        else frame_lfsr[(size_t)s * frames + f] = (uint16_t)state;
         const uint32_t k = draws[(size_t)s * frames + f];
         if (state != 0 && k) { pos = (pos + k) % 65535u; state = seq[pos]; }
     }
+    if (frame_pos) lfsr_state[slot ? slot[s] : s] = (uint16_t)state;
+}
+
+// ---------------------------------------------------------------------------
+// mant_kernel: the mantissa half of the split front end.  A workgroup of six wavefronts takes one frame, staged once
+// into LDS; wavefront b unpacks, dequantises and stores audio block b from its BlkDesc (mant_block, decode_common.h:
+// the code of the one-kernel front ends, rows and coupling coordinates from the workspace).  Nothing carries from one
+// block to the next, so the six run concurrently and a wavefront's dependent chain is a sixth of a frame.
+struct MantParams {
+    const uint8_t *frames;
+    const BlkDesc *desc;        // [S*F][6]
+    const uint8_t *rows;        // [S*F][6] row sets
+    const float *cplco;         // [S*F][6][5][18]
+    const uint32_t *frame_pos;  // [S*F]
+    float *coef;
+    const uint16_t *lfsr_seq;
+    const DecTables *tab;
+    unsigned n_frames;
+    int frame_stride, frame_bytes;
+    int acmod, lfeon, n_in, nfchans;
+};
+
+struct MantLDS {
+    uint32_t desc[100];
+    uint8_t gcode[6][3 * GRING + 4];
+    uint8_t cplbnd[6][20];
+};
+
+#ifndef MANT_LB
+#define MANT_LB 6
+#endif
+__global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
+{
+    __shared__ MantLDS L;
+    extern __shared__ uint32_t frw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int blk = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // consecutive frames on one XCD (its L2 then serves each frame's bytes and rows to the six wavefronts once):
+    // the bijective remap of cdna_hip_programming.md T1
+    unsigned fidx;
+    {
+        const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        fidx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int nw = (P.frame_bytes + 3) >> 2;
+    {
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(P.frames + (size_t)fidx * P.frame_stride);
+        for (int i = tid; i < nw + 6; i += 384) {
+            uint32_t v = 0;
+            if (i < nw) {
+                v = s32[i];
+                const int rem = P.frame_bytes - 4 * i;
+                if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+                v = __builtin_bswap32(v);
+            }
+            frw[i] = v;
+        }
+        if (tid < 100) L.desc[tid] = mant_desc((uint32_t)tid);
+    }
+    __syncthreads();
+    const size_t unit = (size_t)fidx * 6 + blk;
+    const BlkDesc *dp = P.desc + unit;
+    float *cblk = P.coef + unit * P.n_in * 256;
+    const uint32_t flags = dp->flags;
+    if (flags & 1u) {                                           // a failed block leaves zero planes
+        for (int c = 0; c < P.n_in; c++)
+            *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    MantBlk B;
+    B.nf = P.nfchans; B.lfeon = P.lfeon; B.acmod = P.acmod; B.in_lfe = P.lfeon ? 1 : 0;
+    B.chincpl = (int)((flags >> 8) & 31u); B.dithmask = (int)((flags >> 16) & 31u); B.rematflg = (int)((flags >> 24) & 15u);
+    B.cplstrtmant = dp->cplstrt; B.cplendmant = dp->cplend;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { B.endmant[i] = dp->endmant[i]; B.gain[i] = dp->gain[i]; }
+    B.lfe_gain = dp->lfe_gain;
+    if (B.chincpl && lane < 18) {                               // sub-band -> band (parse.c:448-456)
+        const uint32_t below = dp->cplbndstrc & ((1u << lane) - 1u);
+        L.cplbnd[blk][lane] = (uint8_t)(lane - __popc(below));
+    }
+    const uint32_t fpos = P.frame_pos[fidx];
+    const bool lfsr_live = fpos != 0xffffffffu;
+    // (draw k of the block is the state after k+1 steps from here; dither_at takes the position before the first draw)
+    const uint32_t lfsr_i0 = lfsr_live ? (fpos + dp->draw_off) % 65535u : 0u;
+    const uint8_t *rowbase = P.rows + (size_t)fidx * 6 * ROWSET;
+    const float *cc = P.cplco + unit * 90;
+    SegBase sb;
+    sb.bit = dp->bitpos;
+    sb.r3 = sb.r5 = sb.r11 = sb.draw = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    mant_block<false>(B, [&](int slot) { return rowbase + (size_t)dp->rv_exp[slot] * ROWSET + slot * 512; },
+                      [&](int slot) { return reinterpret_cast<const int8_t *>(rowbase + (size_t)dp->rv_bap[slot] * ROWSET + slot * 512 + 256); },
+                      [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.desc, L.gcode[blk], frw, (uint32_t)nw + 2u,
+                      P.tab->qtab, P.lfsr_seq, lfsr_i0, lfsr_live, cblk, sb, lane);
 }
 
 }  // namespace ac3mi
@@ -678,22 +742,57 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
     if (L.n_streams <= 0 || L.frames_per_stream <= 0) return hipSuccess;
     P.frame_draws = L.frame_draws;
     P.frame_lfsr = L.frame_lfsr;
+    P.desc = nullptr;
+    P.rows = nullptr;
+    P.cplco = nullptr;
+    P.frame_pos = nullptr;
     P.dyn_out = L.dyn_out;
     P.dyn_in = L.dyn_in;
     static const int lds_pad = getenv("AC3MI_DEC_LDS_PAD") ? atoi(getenv("AC3MI_DEC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
     const size_t fr_bytes = (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + lds_pad;
+    const unsigned units = (unsigned)L.n_streams * (unsigned)L.frames_per_stream;
+    if (L.split) {
+        // parse (per stream, or per frame + the generator's prefix), then one wavefront per audio block
+        P.desc = (BlkDesc *)L.ws_desc;
+        P.rows = L.ws_rows;
+        P.cplco = L.ws_cplco;
+        P.frame_pos = L.ws_fpos;
+        if (!L.frame_parallel) hipLaunchKernelGGL(decode_kernel<4>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
+        else {
+            hipLaunchKernelGGL(decode_kernel<5>, dim3(units), dim3(64), fr_bytes, stream, P);
+            hipLaunchKernelGGL(lfsr_prefix_kernel, dim3((L.n_streams + 63) / 64), dim3(64), 0, stream, (const uint32_t *)L.frame_draws,
+                               (uint16_t *)nullptr, L.ws_fpos, L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);
+        }
+        MantParams M;
+        M.frames = L.frames;
+        M.desc = (const BlkDesc *)L.ws_desc;
+        M.rows = L.ws_rows;
+        M.cplco = L.ws_cplco;
+        M.frame_pos = L.ws_fpos;
+        M.coef = L.coef;
+        M.lfsr_seq = tab.lfsr_seq;
+        M.tab = tab.dec;
+        M.n_frames = units;
+        M.frame_stride = L.frame_stride;
+        M.frame_bytes = L.frame_bytes;
+        M.acmod = L.acmod;
+        M.lfeon = L.lfeon;
+        M.n_in = P.n_in;
+        M.nfchans = P.nfchans;
+        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, stream, M);
+        return hipGetLastError();
+    }
     if (!L.frame_parallel) {
         hipLaunchKernelGGL(decode_kernel<0>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
         return hipGetLastError();
     }
-    const unsigned units = (unsigned)L.n_streams * (unsigned)L.frames_per_stream;
     DecodeParams C = P;                                 // counting pass: no outputs but the draw counts
     C.tap_exp = nullptr;
     C.tap_bap = nullptr;
     C.dyn_out = nullptr;
     hipLaunchKernelGGL(decode_kernel<1>, dim3(units), dim3(64), fr_bytes, stream, C);
     hipLaunchKernelGGL(lfsr_prefix_kernel, dim3((L.n_streams + 63) / 64), dim3(64), 0, stream, (const uint32_t *)L.frame_draws,
-                       L.frame_lfsr, (const uint16_t *)L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);
+                       L.frame_lfsr, (uint32_t *)nullptr, L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);
     hipLaunchKernelGGL(decode_kernel<2>, dim3(units), dim3(64), fr_bytes, stream, P);
     return hipGetLastError();
 }

@@ -42,6 +42,7 @@ struct DecLDS {
     uint8_t band_of_bin[256];
     int16_t bmask[52];                    // per-band mask of the channel being allocated
     uint32_t desc[100];                   // mant_desc of the row bytes 0..96
+    uint32_t tot[7][4];                   // parse modes: row_totals of the slot's row (a, b) under key start | end << 10 | valid
 };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -127,7 +128,14 @@ struct St {
     uint32_t lfsr;
 };
 
+struct BlkDesc;
 struct DecodeParams {
+    // split front end (decode_kernel<4 / 5> -> mant_kernel): block descriptors, row sets, coupling coordinates, and the
+    // dither generator's position at the start of every frame
+    BlkDesc *desc;
+    uint8_t *rows;
+    float *cplco;
+    uint32_t *frame_pos;
     const uint8_t *frames;
     float *coef;
     uint8_t *blksw;
@@ -523,6 +531,211 @@ __device__ __forceinline__ float mant_value(const BinRegs &R, int j, const uint3
     const float tv = qtab[coded ? qi : 0u];
     const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
     return coded ? tv : pv;
+}
+
+
+// ---------------------------------------------------------------------------
+// One audio block's mantissas: parse.c:813-879.  Shared by decode.hip's one-kernel front ends (rows and coupling
+// coordinates in LDS) and by mant_kernel (rows and coordinates from the parse kernel's workspace in HBM).
+
+// wave-uniform description of the block
+struct MantBlk {
+    int nf, lfeon, acmod, in_lfe;
+    int chincpl, dithmask, rematflg, cplstrtmant, cplendmant;
+    int endmant[5];
+    float gain[5], lfe_gain;
+};
+
+// segment k of the block in bitstream order -> slot (0..4 fbw, 5 lfe, 6 coupling channel): channel 0, the coupling channel
+// right after the first coupled channel, ..., LFE last
+__device__ __forceinline__ int seg_slot(int k, int nf, int chincpl, int cplfirst)
+{
+    if (chincpl) return k <= cplfirst ? k : k == cplfirst + 1 ? 6 : k - 1 < nf ? k - 1 : 5;
+    return k < nf ? k : 5;
+}
+
+// The segments of the block, one step of four bins per lane each (mant_first_half / mant_value).  Ranks of the grouped
+// codes, bit offsets and dither draw indices run on from segment to segment (sb); planes go straight to HBM, 16 bytes per
+// lane.  COUNT: ranks, bit offsets and draw counts only.  erow_of(slot) / brow_of(slot): the slot's exponent / bap row;
+// cplco_of(c, bnd): coupling coordinate of channel c (gain not applied); cplbnd[18]: sub-band -> band.
+template <bool COUNT, class ERow, class BRow, class Cplco>
+__device__ __forceinline__ void mant_block(const MantBlk &B, ERow erow_of, BRow brow_of, Cplco cplco_of, const uint8_t *cplbnd,
+                                           const uint32_t *desc, uint8_t *gcode, const uint32_t *frw, uint32_t frw_last,
+                                           const float *qtab, const uint16_t *lfsr_seq, uint32_t lfsr_i0, bool lfsr_live,
+                                           float *cblk, SegBase &sb, int lane)
+{
+    const int nf = B.nf;
+    const int ncpl_dith = __popc(B.chincpl & B.dithmask);
+    const int remat_end = B.endmant[0] < B.endmant[1] ? B.endmant[0] : B.endmant[1];
+    // Only a damaged frame can put rematrixed bins inside the coupling range (a coupled channel that reuses its
+    // exponents keeps the previous block's end): liba52 rematrixes the planes as they stand after coupling and
+    // zeroing (parse.c:837-865), so that case runs as a pass of its own after the segments.
+    const bool remat_late = B.acmod == 2 && B.rematflg != 0 && B.chincpl != 0 && remat_end > B.cplstrtmant;
+    const int cplfirst = B.chincpl ? __builtin_ctz(B.chincpl) : 99;
+    const int nseg = nf + (B.chincpl ? 1 : 0) + (B.lfeon ? 1 : 0);
+    for (int k = 0; k < nseg; k++) {
+        const int slot = seg_slot(k, nf, B.chincpl, cplfirst);
+        int start = 0, end, draws = 0;
+        float g = 0.f;
+        if (slot < 5) {
+            end = slot == 0 ? B.endmant[0] : slot == 1 ? B.endmant[1] : slot == 2 ? B.endmant[2] : slot == 3 ? B.endmant[3] : B.endmant[4];
+            g = slot == 0 ? B.gain[0] : slot == 1 ? B.gain[1] : slot == 2 ? B.gain[2] : slot == 3 ? B.gain[3] : B.gain[4];
+            draws = (B.dithmask >> slot) & 1;
+        } else if (slot == 5) {
+            end = 7;
+            g = B.lfe_gain;
+        } else {
+            start = B.cplstrtmant;
+            end = B.cplendmant;
+            draws = ncpl_dith;
+        }
+        sb.mult = draws;
+        BinRegs R;
+        const SegTotals T = mant_first_half<GRING, GRING - 1, COUNT>(erow_of(slot), brow_of(slot), desc, gcode, frw,
+                                                                    frw_last, start, end, slot == 5 ? LFE_ROW / 4 : 64, sb, R, lane);
+        sb.bit += T.bits;
+        sb.r3 += T.n3;
+        sb.r5 += T.n5;
+        sb.r11 += T.n11;
+        sb.draw += T.draws;
+        if (COUNT) continue;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (slot < 6) {
+            float out[4];
+            int cd = R.cd;
+            const bool dith = draws != 0 && lfsr_live;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bin = 4 * lane + j;
+                const bool zero = bin < end && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
+                const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
+                float q = mant_value<GRING, GRING - 1>(R, j, desc, gcode, qtab);
+                if (dith && __any(zero)) {                // wave-uniform: no table access when no lane draws
+                    const float dv = (float)dither_at(lfsr_seq, lfsr_i0, cd);
+                    q = zero ? dv : q;
+                }
+                cd += (zero && draws) ? 1 : 0;
+                out[j] = q * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
+            }
+            float *plane = cblk + (slot == 5 ? 0 : slot + B.in_lfe) * 256;
+            if (slot == 1 && B.acmod == 2 && B.rematflg != 0 && !remat_late) {
+                // rematrix: parse.c:837-865.  Channel 0's bins were stored by this same lane.
+                float4 a4 = *reinterpret_cast<const float4 *>(plane - 256 + 4 * lane);
+                float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int bin = 4 * lane + j;
+                    const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
+                    // (liba52's loop is a do-while, parse.c:846-862: with the first band's flag set it rematrixes bin 13
+                    // even when the channels end at or below it - a damaged frame whose block 0 reuses exponents)
+                    if (bin >= 13 && (bin < remat_end || (bin == 13 && remat_end <= 13)) && ((B.rematflg >> band) & 1)) {
+                        const float x = a[j], v = out[j];
+                        a[j] = x + v;
+                        out[j] = x - v;
+                    }
+                }
+                *reinterpret_cast<float4 *>(plane - 256 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            if (slot < 5 && ((B.chincpl >> slot) & 1)) {
+                // a coupled channel: its own bins, zeros up to the coupling range (a damaged frame can leave a gap
+                // there: liba52 then keeps the previous block's PCM, its buffer being transformed in place; here
+                // zeros) and from the END OF THE COUPLING RANGE on - also where a damaged frame left the channel's own
+                // end (it keeps the previous block's when the exponents are reused) beyond it: liba52 zeroes from
+                // cplendmant (parse.c:826-834).  The coupling channel's share in between is written by that segment,
+                // which comes after the first coupled channel and before the others: as in liba52, a later coupled
+                // channel's own bins inside the range win over the coupling channel's, the first one's lose.
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int bin = 4 * lane + j;
+                    if (bin < end || bin < B.cplstrtmant || bin >= B.cplendmant) plane[bin] = bin >= B.cplendmant ? 0.f : out[j];
+                }
+            } else {
+                *reinterpret_cast<float4 *>(plane + 4 * lane) = make_float4(out[0], out[1], out[2], out[3]);
+            }
+        } else {
+            // coupling channel: parse.c:435-556
+            int cd = R.cd;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bin = 4 * lane + j;
+                const bool in = bin >= start && bin < end;
+                const bool zero = in && ((R.bap4 >> (8 * j)) & 0xffu) == 0u;
+                const int e = (int)((R.exp4 >> (8 * j)) & 0xffu);
+                const float m = mant_value<GRING, GRING - 1>(R, j, desc, gcode, qtab) * sf_of(e);
+                const int bnd = cplbnd[in ? (bin - start) / 12 : 0];
+                int cdc = cd;
+                for (int c = 0; c < nf; c++) {
+                    if (!((B.chincpl >> c) & 1)) continue;
+                    const float gc = c == 0 ? B.gain[0] : c == 1 ? B.gain[1] : c == 2 ? B.gain[2] : c == 3 ? B.gain[3] : B.gain[4];
+                    const float co = cplco_of(c, bnd) * gc;
+                    float v = m * co;
+                    if (zero) {
+                        v = 0.f;
+                        if ((B.dithmask >> c) & 1) { v = (sf_of(e) * co) * (float)(lfsr_live ? dither_at(lfsr_seq, lfsr_i0, cdc) : 0); cdc++; }
+                    }
+                    if (in) cblk[(c + B.in_lfe) * 256 + bin] = v;
+                }
+                cd += zero ? draws : 0;
+            }
+        }
+    }
+    if (!COUNT && remat_late) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        volatile float *p0 = cblk + (size_t)B.in_lfe * 256, *p1 = p0 + 256;
+        for (int bin = 13 + lane; bin < remat_end; bin += 64) {
+            const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
+            if ((B.rematflg >> band) & 1) {
+                const float a = p0[bin], v = p1[bin];
+                p0[bin] = a + v;
+                p1[bin] = a - v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The split front end: decode_kernel<4 / 5> parses (side information, exponents, bit allocation) and leaves, per audio
+// block, this descriptor plus the exponent / bap rows that changed; mant_kernel (one wavefront per block) unpacks and
+// dequantises from them.  What a block needs of the blocks before it is all here: where its mantissas start, how many
+// dither draws came before, which rows are current.
+
+struct alignas(16) BlkDesc {
+    uint32_t bitpos;            // first mantissa bit of the block
+    uint32_t draw_off;          // dither draws of the frame before this block
+    uint32_t flags;             // bit 0: the block failed (zero planes); 8-12 chincpl; 16-20 dither flags; 24-27 rematflg
+    uint32_t cplbndstrc;
+    uint16_t endmant[5], cplstrt, cplend, pad0;
+    uint8_t rv_exp[8], rv_bap[8];   // block of THIS frame whose row holds the slot's current exponents / bap
+    float gain[5], lfe_gain;        // parse.c:810-811 (dynamic range folded in); LFE: 0 when it is not an output
+    uint32_t pad1[2];
+};
+static_assert(sizeof(BlkDesc) == 80, "BlkDesc layout");
+
+constexpr int ROWSET = 7 * 512;         // bytes of one (frame, block) row set: 7 slots x (256 exponents + 256 row bytes)
+
+// totals of one slot's row over [start, end): a = plain bits | 3-level members << 13 | 5-level members << 22,
+// b = 11-level members | zero-bit bins << 9.  Wave-uniform.
+struct RowTotals { uint32_t a, b; };
+__device__ __forceinline__ RowTotals row_totals(const int8_t *brow, int start, int end, int lanes4, int lane)
+{
+    const uint32_t bap4 = lane < lanes4 ? *reinterpret_cast<const uint32_t *>(brow + 4 * lane) : 0u;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int bin = 4 * lane + j;
+        const uint32_t act = (uint32_t)(bin >= start) & (uint32_t)(bin < end);
+        const uint32_t x = (bap4 >> (8 * j)) & 0xffu, k1 = x >> 5;
+        a += act * ((x & 31u) + ((uint32_t)(k1 == 1u) << 13) + ((uint32_t)(k1 == 2u) << 22));
+        b += act * ((uint32_t)(k1 == 3u) + ((uint32_t)(x == 0u) << 9));
+    }
+    RowTotals t;
+    t.a = wave_sum_u32(a);
+    t.b = wave_sum_u32(b);
+    return t;
 }
 
 }  // namespace ac3mi

@@ -221,7 +221,8 @@ def test_large_batch_goes_through_the_chunk_pipeline(engine):
 @pytest.mark.parametrize("source", ["encoder", "packer"])
 def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
     """ac3mi_set_decode_mode: 1 = one wavefront per stream (frames in order), 2 = counting pass + LFSR prefix + one
-    wavefront per frame.  Same PCM, status, taps and final LFSR state, bit for bit - on encoder output (dither-heavy
+    wavefront per frame, 3 = one workgroup per stream, 4 / 5 = the split front end (parse kernel per stream / per frame +
+    generator prefix, then one wavefront per audio block).  Same PCM, status, taps and final LFSR state, bit for bit - on encoder output (dither-heavy
     "quiet" streams included) and on packer streams with coupling, rematrixing, delta bit allocation."""
     import torch
     from tests import packer
@@ -243,7 +244,7 @@ def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
     n_out, _ = engine.decode_planes(desc)
     res = {}
     try:
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4, 5):
             engine.set_decode_mode(mode)
             delay = torch.zeros((S, n_out, 128), dtype=torch.float32, device="cuda")
             lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
@@ -258,7 +259,7 @@ def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
         import os
         engine.set_decode_mode(int(os.environ.get("AC3MI_DECODE_MODE", "0")))
     assert (res[1][1] & 0x1ff).max() == 0
-    for other in (2, 3):                                 # 3 = one workgroup per stream (decode_wg.hip), planes written out for the taps
+    for other in (2, 3, 4, 5):                           # 3 = one workgroup per stream (decode_wg.hip), planes written out for the taps
         for a, b in zip(res[1], res[other]):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), other
 

@@ -184,7 +184,7 @@ def test_status_flags_frames_whose_block_0_reuses_unsent_state(wg_engine):
     padded[:, 0, :fb] = frames
     desc = pkg.DecodeDesc(flags=7 | 16, level=1.0, bias=0.0, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
     res = {}
-    for mode in (1, 3):
+    for mode in (1, 3, 4):
         wg_engine.set_decode_mode(mode)
         delay = torch.zeros((S, 6, 128), dtype=torch.float32, device="cuda")
         lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
@@ -199,3 +199,9 @@ def test_status_flags_frames_whose_block_0_reuses_unsent_state(wg_engine):
     assert np.array_equal(a[2][ok].view(np.uint32), b[2][ok].view(np.uint32))
     flagged = (a[0] & 0x200) != 0
     assert flagged.any() and not flagged[:6].any()           # some damaged frames, never the undamaged controls
+    # the split front end (mode 4) against the one-kernel one (mode 1): the same code over the same state, every frame -
+    # the failed ones too
+    c = res[4]
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[3], c[3])
+    assert np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+    assert np.array_equal(a[2].view(np.uint32), c[2].view(np.uint32))
