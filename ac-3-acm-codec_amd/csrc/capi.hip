@@ -413,13 +413,16 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipMemcpy(ctx->tab.tw_short, tws.data(), 128 * sizeof(float2), hipMemcpyHostToDevice));
     {
         DecTables dt;
-        std::vector<uint16_t> seq(65535), idx(65536);
+        // (the sequence runs on for LFSR_EXT entries past its period: mant_kernel indexes a block's draws without a modulo)
+        constexpr int LFSR_EXT = 16384;
+        std::vector<uint16_t> seq(65535 + LFSR_EXT), idx(65536);
         build_dec_tables(&dt, seq.data(), idx.data());
+        for (int i = 0; i < LFSR_EXT; i++) seq[65535 + i] = seq[i];
         HIPCHK(ctx, hipMalloc(&ctx->tab.dec, sizeof dt));
-        HIPCHK(ctx, hipMalloc(&ctx->tab.lfsr_seq, 65535 * sizeof(uint16_t)));
+        HIPCHK(ctx, hipMalloc(&ctx->tab.lfsr_seq, seq.size() * sizeof(uint16_t)));
         HIPCHK(ctx, hipMalloc(&ctx->tab.lfsr_idx, 65536 * sizeof(uint16_t)));
         HIPCHK(ctx, hipMemcpy(ctx->tab.dec, &dt, sizeof dt, hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_seq, seq.data(), 65535 * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_seq, seq.data(), seq.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(ctx->tab.lfsr_idx, idx.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     {

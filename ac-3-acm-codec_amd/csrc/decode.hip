@@ -20,6 +20,7 @@
 //
 // Built with -ffp-contract=off: coefficient values are bit-identical to liba52's.
 #include "decode_common.h"
+#include "mant2.h"
 
 namespace ac3mi {
 
@@ -622,8 +623,9 @@ struct MantParams {
 };
 
 struct MantLDS {
-    uint32_t desc[100];
-    uint8_t gcode[6][3 * GRING + 4];
+    uint4 dsc[M2_NDESC];
+    float qtab[760];
+    uint8_t ring[6][M2_LDS_WAVE];
     uint8_t cplbnd[6][20];
 };
 
@@ -643,6 +645,11 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
         const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
         fidx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
+    const size_t unit = (size_t)fidx * 6 + blk;
+    // the block's descriptor: five 16-byte loads of one address, in flight while the frame is staged
+    const uint4 *dq = reinterpret_cast<const uint4 *>(P.desc + unit);
+    const uint4 w0v = dq[0], w1v = dq[1], w2v = dq[2], w3v = dq[3], w4v = dq[4];
+    const uint32_t fposv = P.frame_pos[fidx];
     const int nw = (P.frame_bytes + 3) >> 2;
     {
         const uint32_t *s32 = reinterpret_cast<const uint32_t *>(P.frames + (size_t)fidx * P.frame_stride);
@@ -656,13 +663,12 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
             }
             frw[i] = v;
         }
-        if (tid < 100) L.desc[tid] = mant_desc((uint32_t)tid);
+        if (tid < M2_NDESC) L.dsc[tid] = mant_desc2((uint32_t)tid);
+        for (int i = tid; i < 760; i += 384) L.qtab[i] = P.tab->qtab[i];
     }
     __syncthreads();
-    const size_t unit = (size_t)fidx * 6 + blk;
-    const BlkDesc *dp = P.desc + unit;
     float *cblk = P.coef + unit * P.n_in * 256;
-    const uint32_t flags = dp->flags;
+    const uint32_t flags = rfl(w0v.z);
     if (flags & 1u) {                                           // a failed block leaves zero planes
         for (int c = 0; c < P.n_in; c++)
             *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -671,30 +677,31 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
     MantBlk B;
     B.nf = P.nfchans; B.lfeon = P.lfeon; B.acmod = P.acmod; B.in_lfe = P.lfeon ? 1 : 0;
     B.chincpl = (int)((flags >> 8) & 31u); B.dithmask = (int)((flags >> 16) & 31u); B.rematflg = (int)((flags >> 24) & 15u);
-    B.cplstrtmant = dp->cplstrt; B.cplendmant = dp->cplend;
-#pragma unroll
-    for (int i = 0; i < 5; i++) { B.endmant[i] = dp->endmant[i]; B.gain[i] = dp->gain[i]; }
-    B.lfe_gain = dp->lfe_gain;
+    {
+        const uint32_t a = rfl(w1v.x), b = rfl(w1v.y), c = rfl(w1v.z), d = rfl(w1v.w);
+        B.endmant[0] = (int)(a & 0xffffu); B.endmant[1] = (int)(a >> 16); B.endmant[2] = (int)(b & 0xffffu); B.endmant[3] = (int)(b >> 16);
+        B.endmant[4] = (int)(c & 0xffffu); B.cplstrtmant = (int)(c >> 16); B.cplendmant = (int)(d & 0xffffu);
+    }
+    B.gain[0] = __uint_as_float(rfl(w3v.x)); B.gain[1] = __uint_as_float(rfl(w3v.y)); B.gain[2] = __uint_as_float(rfl(w3v.z));
+    B.gain[3] = __uint_as_float(rfl(w3v.w)); B.gain[4] = __uint_as_float(rfl(w4v.x)); B.lfe_gain = __uint_as_float(rfl(w4v.y));
     if (B.chincpl && lane < 18) {                               // sub-band -> band (parse.c:448-456)
-        const uint32_t below = dp->cplbndstrc & ((1u << lane) - 1u);
+        const uint32_t below = rfl(w0v.w) & ((1u << lane) - 1u);
         L.cplbnd[blk][lane] = (uint8_t)(lane - __popc(below));
     }
-    const uint32_t fpos = P.frame_pos[fidx];
+    const uint32_t fpos = rfl(fposv);
     const bool lfsr_live = fpos != 0xffffffffu;
-    // (draw k of the block is the state after k+1 steps from here; dither_at takes the position before the first draw)
-    const uint32_t lfsr_i0 = lfsr_live ? (fpos + dp->draw_off) % 65535u : 0u;
+    const uint32_t i0 = lfsr_live ? (fpos + rfl(w0v.y)) % 65535u : 0u;            // the generator's position before the block's first draw
+    const uint64_t rve = (uint64_t)rfl(w2v.x) | ((uint64_t)rfl(w2v.y) << 32), rvb = (uint64_t)rfl(w2v.z) | ((uint64_t)rfl(w2v.w) << 32);
     const uint8_t *rowbase = P.rows + (size_t)fidx * 6 * ROWSET;
     const float *cc = P.cplco + unit * 90;
-    SegBase sb;
-    sb.bit = dp->bitpos;
-    sb.r3 = sb.r5 = sb.r11 = sb.draw = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    mant_block<false>(B, [&](int slot) { return rowbase + (size_t)dp->rv_exp[slot] * ROWSET + slot * 512; },
-                      [&](int slot) { return reinterpret_cast<const int8_t *>(rowbase + (size_t)dp->rv_bap[slot] * ROWSET + slot * 512 + 256); },
-                      [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.desc, L.gcode[blk], frw, (uint32_t)nw + 2u,
-                      P.tab->qtab, P.lfsr_seq, lfsr_i0, lfsr_live, cblk, sb, lane);
+    auto fetch = [&](int slot) -> uint2 {
+        const uint8_t *er = rowbase + (size_t)((rve >> (8 * slot)) & 7u) * ROWSET + slot * 512;
+        const uint8_t *br = rowbase + (size_t)((rvb >> (8 * slot)) & 7u) * ROWSET + slot * 512 + 256;
+        if (slot == 5) return lane < 7 ? make_uint2(br[lane], er[lane]) : make_uint2(1u, 0u);
+        return make_uint2(reinterpret_cast<const uint32_t *>(br)[lane], reinterpret_cast<const uint32_t *>(er)[lane]);
+    };
+    mant_block2(B, fetch, [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.dsc, L.ring[blk], frw, (uint32_t)nw + 2u,
+                L.qtab, reinterpret_cast<const int16_t *>(P.lfsr_seq) + 1 + i0, lfsr_live, cblk, rfl(w0v.x), lane);
 }
 
 }  // namespace ac3mi
