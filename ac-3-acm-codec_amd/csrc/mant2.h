@@ -110,17 +110,30 @@ __device__ __forceinline__ void seg2_first(uint32_t bytes4, const uint4 *dsc, ui
     }
 }
 
-// dequantised value of bin j before the exponent / gain scale (0 for a zero-bit bin)
+// dequantised values of the lane's bins before the exponent / gain scale (0 for a zero-bit bin).  The ring and table reads
+// of all bins are issued together (the empty asm pins each code where it is read: the compiler otherwise sinks every
+// ring read into a branch of its own, one LDS round trip per bin).
 template <int NB>
-__device__ __forceinline__ float seg2_value(const Bins2<NB> &R, int j, const uint8_t *ring, const float *qtab)
+__device__ __forceinline__ void seg2_values(const Bins2<NB> &R, const uint8_t *ring, const float *qtab, float *q)
 {
-    const uint32_t code = ring[R.rs[j] & 0xffffu];
-    const uint32_t per = (R.dy[j] >> 16) & 0xffu, nbp = R.dy[j] & 0xffu;
-    const uint32_t sel = per ? code * per + (R.rs[j] >> 16) : R.raw[j];
-    const uint32_t coded = R.dw[j] >> 24;
-    const float tv = qtab[coded ? (R.dz[j] >> 16) + sel : 0u];
-    const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
-    return coded ? tv : pv;
+    uint32_t code[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) code[j] = ring[R.rs[j] & 0xffffu];
+#pragma unroll
+    for (int j = 0; j < NB; j++) { asm volatile("" : "+v"(code[j])); code[j] &= 0xffu; }
+    float tv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const uint32_t per = (R.dy[j] >> 16) & 0xffu;
+        const uint32_t sel = per ? code[j] * per + (R.rs[j] >> 16) : R.raw[j];
+        tv[j] = qtab[(R.dw[j] >> 24) ? (R.dz[j] >> 16) + sel : 0u];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const uint32_t nbp = R.dy[j] & 0xffu;
+        const float pv = (float)(((int32_t)(R.raw[j] << ((32u - nbp) & 31u))) >> 16);      // two's complement fraction, scaled by 2^15
+        q[j] = (R.dw[j] >> 24) ? tv[j] : pv;
+    }
 }
 
 // dither value of draw index i (position along the generator's cycle, table extended past the period): parse.c:310-319
@@ -156,7 +169,8 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, Cplco
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float q = seg2_value<1>(R, 0, ring, qtab);
+            float q;
+            seg2_values<1>(R, ring, qtab, &q);
             const float v = q * (sf_of((int)(cur.y & 0xffu)) * B.lfe_gain);
             const float z = 0.f * (sf_of(0) * B.lfe_gain);          // what the four-bin pass gives the bins past the seventh
             if (lane < 8) cblk[lane] = lane < 7 ? v : z;
@@ -190,21 +204,20 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, Cplco
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (slot < 5) {
-            float out[4];
-            uint32_t cd = R.cd;
+            float out[4], qv[4];
+            seg2_values<4>(R, ring, qtab, qv);
             const bool dith = draws != 0 && lfsr_live;
-            const bool anyz = dith && __any(((R.dw[0] | R.dw[1] | R.dw[2] | R.dw[3]) >> 16) & 1u);     // wave-uniform: no table access when no lane draws
+            const uint32_t z0 = (R.dw[0] >> 16) & 0xffu, z1 = (R.dw[1] >> 16) & 0xffu, z2 = (R.dw[2] >> 16) & 0xffu, z3 = (R.dw[3] >> 16) & 0xffu;
+            if (dith && __any((z0 | z1 | z2 | z3) != 0u)) {       // wave-uniform: no table access when no lane draws
+                // the lane's draws are consecutive: bin j takes draw cd + (zero-bit bins before it in the lane)
+                const int16_t *sp = seq1 + R.cd;
+                const float d0 = dither2(sp, 0), d1 = dither2(sp, z0), d2 = dither2(sp, z0 + z1), d3 = dither2(sp, z0 + z1 + z2);
+                qv[0] = z0 ? d0 : qv[0]; qv[1] = z1 ? d1 : qv[1]; qv[2] = z2 ? d2 : qv[2]; qv[3] = z3 ? d3 : qv[3];
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t zero = (R.dw[j] >> 16) & 0xffu;
                 const int e = (int)((cur.y >> (8 * j)) & 0xffu);
-                float q = seg2_value<4>(R, j, ring, qtab);
-                if (anyz) {
-                    const float dv = dither2(seq1, cd);
-                    q = zero ? dv : q;
-                }
-                cd += zero * (uint32_t)draws;
-                out[j] = q * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
+                out[j] = qv[j] * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
             }
             float *plane = cblk + (slot + B.in_lfe) * 256;
             if (slot == 1 && B.acmod == 2 && B.rematflg != 0 && !remat_late) {
@@ -236,13 +249,15 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, Cplco
         } else {
             // coupling channel: parse.c:435-556
             uint32_t cd = R.cd;
+            float qv[4];
+            seg2_values<4>(R, ring, qtab, qv);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int bin = 4 * lane + j;
                 const bool in = bin >= start && bin < end;
                 const bool zero = ((R.dw[j] >> 16) & 0xffu) != 0u;          // (only bins of the segment carry the flag)
                 const int e = (int)((cur.y >> (8 * j)) & 0xffu);
-                const float m = seg2_value<4>(R, j, ring, qtab) * sf_of(e);
+                const float m = qv[j] * sf_of(e);
                 const int bnd = cplbnd[in ? (bin - start) / 12 : 0];
                 uint32_t cdc = cd;
                 for (int c = 0; c < nf; c++) {
