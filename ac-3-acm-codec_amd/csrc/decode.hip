@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
         // parse modes: rows of this frame's row sets not written yet (bit = slot), and the block that holds each slot's
         // current row (4 bits per slot)
         int dirty_exp = 0x7f, dirty_bap = 0x7f;
-        uint32_t rv_exp = 0, rv_bap = 0;
+        uint32_t rv_exp = 0, rv_bap = 0;            // lane = slot
         if (MODE == 4) frame_draws = 0;
 
         DK_T0();
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        Rd rd{FB, 0, ~0u, 0, 0};
+        Rd rd{FB, 0, 0, 0};
         // ---- a52_syncinfo (parse.c:86-129) + a52_frame (parse.c:131-205) ----
         bool hdr_ok = true;
         {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
         }
         if (hdr_ok) {
             int acmod = st.acmod;
-            rd.pos = 6 * 8 + 3;
+            rd.seek(6 * 8 + 3);
             if (acmod == 2 && rd.get(2) == 2) acmod = 10;                 // dsurmod -> DOLBY
             st.clev = st.slev = 0.f;
             if ((acmod & 1) && acmod != 1) st.clev = k_clev[rd.get(2)];
@@ -215,8 +215,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
             const int in_lfe = P.lfeon ? 1 : 0;
             int err = frame_dead ? 1 : 0;
             int blkswm = 0, dithmask = 0;
-            BlkDesc bd;
-            bd.flags = 1u;
+            bool bd_ok = false;
             float gain[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             const int nf = st.nf;
 
@@ -307,8 +306,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
                     const int e0 = rd.get(4) << 1;
                     redo = 64;
-                    if (read_exponents(FB, rd.pos, cplexpstr, ngrp, e0, L.exp + row_off(6) + st.cplstrtmant, lane)) { err = 1; break; }
-                    rd.pos += 7 * ngrp;
+                    if (read_exponents(FB, rd.pos(), cplexpstr, ngrp, e0, L.exp + row_off(6) + st.cplstrtmant, lane)) { err = 1; break; }
+                    rd.skip(7 * ngrp);
                 }
 #pragma unroll
                 for (int i = 0; i < 5; i++) {
@@ -318,8 +317,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                         redo |= 1 << i;
                         const int e0 = rd.get(4);
                         if (lane == 0) L.exp[row_off(i)] = (uint8_t)e0;
-                        if (read_exponents(FB, rd.pos, es, ngrp, e0, L.exp + row_off(i) + 1, lane)) err = 1;
-                        rd.pos += 7 * ngrp;
+                        if (read_exponents(FB, rd.pos(), es, ngrp, e0, L.exp + row_off(i) + 1, lane)) err = 1;
+                        rd.skip(7 * ngrp);
                         rd.get(2);                                          // gainrng
                     }
                 }
@@ -328,8 +327,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     redo |= 32;
                     const int e0 = rd.get(4);
                     if (lane == 0) L.exp[row_off(5)] = (uint8_t)e0;
-                    if (read_exponents(FB, rd.pos, lfeexpstr, 2, e0, L.exp + row_off(5) + 1, lane)) { err = 1; break; }
-                    rd.pos += 14;
+                    if (read_exponents(FB, rd.pos(), lfeexpstr, 2, e0, L.exp + row_off(5) + 1, lane)) { err = 1; break; }
+                    rd.skip(14);
                 }
 
                 DK_LAP(2);
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                 }
                 if (rd.get(1)) {                                            // skip field
                     const int n = rd.get(9);
-                    rd.pos += 8 * n;
+                    rd.skip(8 * n);
                 }
             } while (0);
 
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     L.cplbnd[lane] = (uint8_t)(lane - __popc(below));
                 }
                 SegBase sb;
-                sb.bit = rd.pos;
+                sb.bit = rd.pos();
                 sb.r3 = sb.r5 = sb.r11 = sb.draw = 0;
                 if constexpr (!PARSE) {
                     MantBlk B;
@@ -491,63 +490,85 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     if (MODE != 1 && lfsr_live && sb.draw) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)sb.draw) % 65535u];
                 } else {
                     // parse only: the totals of every segment's row (cached per slot while row and range stay) give the bits and
-                    // the dither draws of the block; rows that changed go to the workspace; the descriptor names them
+                    // the dither draws of the block; rows that changed go to the workspace; the descriptor names them.
+                    // Lane k takes segment k (the scalar unit is this kernel's bottleneck: a loop over the segments on
+                    // wave-uniform values costs 600 scalar instructions per block, this form about 80 vector ones).
                     const int cplfirst = st.chincpl ? __builtin_ctz(st.chincpl) : 99;
                     const int nseg = nf + (st.chincpl ? 1 : 0) + (st.lfeon ? 1 : 0);
                     const int ncpl_dith = __popc(st.chincpl & dithmask);
-                    uint8_t *rowset = P.rows + (fidx * 6 + blk) * (size_t)ROWSET;
-                    for (int k = 0; k < nseg; k++) {
-                        const int slot = seg_slot(k, nf, st.chincpl, cplfirst);
-                        int start = 0, end, mult = 0;
-                        if (slot < 5) {
-                            end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2] : slot == 3 ? st.endmant[3] : st.endmant[4];
-                            mult = (dithmask >> slot) & 1;
-                        } else if (slot == 5) end = 7;
-                        else { start = st.cplstrtmant; end = st.cplendmant; mult = ncpl_dith; }
-                        const int lanes4 = slot == 5 ? LFE_ROW / 4 : 64;
-                        const uint32_t key = 0x80000000u | (uint32_t)start | ((uint32_t)end << 10);
-                        RowTotals T;
-                        if (rfl(L.tot[slot][2]) == key) { T.a = rfl(L.tot[slot][0]); T.b = rfl(L.tot[slot][1]); }
-                        else {
-                            T = row_totals(L.bap + row_off(slot), start, end, lanes4, lane);
-                            if (lane == 0) { L.tot[slot][0] = T.a; L.tot[slot][1] = T.b; L.tot[slot][2] = key; }
-                        }
-                        const int n3 = (int)((T.a >> 13) & 511u), n5 = (int)(T.a >> 22), n11 = (int)(T.b & 511u), nz = (int)(T.b >> 9);
+                    const int k = lane;
+                    const int slot_l = st.chincpl ? (k <= cplfirst ? k : k == cplfirst + 1 ? 6 : k - 1 < nf ? k - 1 : 5) : (k < nf ? k : 5);
+                    const bool seg_l = k < nseg;
+                    const int end_l = slot_l == 0 ? st.endmant[0] : slot_l == 1 ? st.endmant[1] : slot_l == 2 ? st.endmant[2] : slot_l == 3 ? st.endmant[3]
+                                    : slot_l == 4 ? st.endmant[4] : slot_l == 5 ? 7 : st.cplendmant;
+                    const int start_l = slot_l == 6 ? st.cplstrtmant : 0;
+                    const int mult_l = slot_l < 5 ? (dithmask >> slot_l) & 1 : slot_l == 6 ? ncpl_dith : 0;
+                    const uint32_t key_l = 0x80000000u | (uint32_t)start_l | ((uint32_t)end_l << 10);
+                    uint32_t ca = L.tot[slot_l][0], cb = L.tot[slot_l][1];
+                    for (unsigned long long miss = __ballot(seg_l && L.tot[slot_l][2] != key_l); miss; miss &= miss - 1) {
+                        const int k0 = __builtin_ctzll(miss);
+                        const int s0 = __builtin_amdgcn_readlane(slot_l, k0);
+                        const RowTotals T = row_totals(L.bap + row_off(s0), __builtin_amdgcn_readlane(start_l, k0), __builtin_amdgcn_readlane(end_l, k0),
+                                                       s0 == 5 ? LFE_ROW / 4 : 64, lane);
+                        if (lane == k0) { ca = T.a; cb = T.b; L.tot[s0][0] = T.a; L.tot[s0][1] = T.b; L.tot[s0][2] = key_l; }
+                    }
+                    {
+                        const uint32_t n3 = seg_l ? (ca >> 13) & 511u : 0u, n5 = seg_l ? ca >> 22 : 0u, n11 = seg_l ? cb & 511u : 0u;
+                        const uint32_t nz = seg_l ? cb >> 9 : 0u, plain = seg_l ? ca & 0x1fffu : 0u;
+                        // 3/5/11-level members of the block before the segment
+                        const uint32_t own35 = n3 | (n5 << 16), p35 = wave_incl_scan_u32(own35) - own35, r11 = wave_incl_scan_u32(n11) - n11;
+                        const uint32_t r3 = p35 & 0xffffu, r5 = p35 >> 16;
                         // a grouped code takes its bits where the member of rank 0 mod 3 (mod 2) stands
-                        const int o3 = (sb.r3 + n3 + 2) / 3 - (sb.r3 + 2) / 3, o5 = (sb.r5 + n5 + 2) / 3 - (sb.r5 + 2) / 3;
-                        const int o11 = ((sb.r11 + n11 + 1) >> 1) - ((sb.r11 + 1) >> 1);
-                        sb.bit += (T.a & 0x1fffu) + 5u * (uint32_t)o3 + 7u * (uint32_t)(o5 + o11);
-                        sb.r3 += n3; sb.r5 += n5; sb.r11 += n11;
-                        sb.draw += nz * mult;
-                        if ((dirty_exp >> slot) & 1) {
-                            if (lane < lanes4) *reinterpret_cast<uint32_t *>(rowset + slot * 512 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.exp + row_off(slot) + 4 * lane);
-                            dirty_exp &= ~(1 << slot);
-                            rv_exp = (rv_exp & ~(7u << (4 * slot))) | ((uint32_t)blk << (4 * slot));
+                        auto div3 = [](uint32_t x) { return (x * 0xaaabu) >> 17; };
+                        const uint32_t o3 = div3(r3 + n3 + 2u) - div3(r3 + 2u), o5 = div3(r5 + n5 + 2u) - div3(r5 + 2u);
+                        const uint32_t o11 = ((r11 + n11 + 1u) >> 1) - ((r11 + 1u) >> 1);
+                        const uint32_t bits_l = plain + 5u * o3 + 7u * (o5 + o11);
+                        const uint32_t tot = wave_sum_u32(bits_l | ((nz * (uint32_t)mult_l) << 16));
+                        sb.bit += tot & 0xffffu;
+                        sb.draw = (int)(tot >> 16);
+                    }
+                    {
+                        uint8_t *rowset = P.rows + (fidx * 6 + blk) * (size_t)ROWSET;
+                        const int used = ((1 << nf) - 1) | (st.lfeon ? 32 : 0) | (st.chincpl ? 64 : 0);
+                        const int we = dirty_exp & used, wb = dirty_bap & used;
+                        for (int m = we; m; m &= m - 1) {
+                            const int s0 = __builtin_ctz(m);
+                            if (lane < (s0 == 5 ? LFE_ROW / 4 : 64))
+                                *reinterpret_cast<uint32_t *>(rowset + s0 * 512 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.exp + row_off(s0) + 4 * lane);
                         }
-                        if ((dirty_bap >> slot) & 1) {
-                            if (lane < lanes4) *reinterpret_cast<uint32_t *>(rowset + slot * 512 + 256 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.bap + row_off(slot) + 4 * lane);
-                            dirty_bap &= ~(1 << slot);
-                            rv_bap = (rv_bap & ~(7u << (4 * slot))) | ((uint32_t)blk << (4 * slot));
+                        for (int m = wb; m; m &= m - 1) {
+                            const int s0 = __builtin_ctz(m);
+                            if (lane < (s0 == 5 ? LFE_ROW / 4 : 64))
+                                *reinterpret_cast<uint32_t *>(rowset + s0 * 512 + 256 + 4 * lane) = *reinterpret_cast<const uint32_t *>(L.bap + row_off(s0) + 4 * lane);
                         }
+                        dirty_exp &= ~we;
+                        dirty_bap &= ~wb;
+                        // lane = slot: the block of this frame that holds the slot's current rows
+                        rv_exp = ((we >> lane) & 1) ? (uint32_t)blk : rv_exp;
+                        rv_bap = ((wb >> lane) & 1) ? (uint32_t)blk : rv_bap;
                     }
                     if (st.chincpl) {
                         float *cc = P.cplco + (fidx * 6 + blk) * 90;
                         cc[lane] = (&L.cplco[0][0])[lane];
                         if (lane < 26) cc[64 + lane] = (&L.cplco[0][0])[64 + lane];
                     }
-                    bd.bitpos = rd.pos;
-                    bd.draw_off = frame_draws;
-                    bd.flags = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg << 24);
-                    bd.cplbndstrc = st.cplbndstrc;
-#pragma unroll
-                    for (int i = 0; i < 5; i++) { bd.endmant[i] = (uint16_t)st.endmant[i]; bd.gain[i] = gain[i]; }
-                    bd.cplstrt = (uint16_t)st.cplstrtmant;
-                    bd.cplend = (uint16_t)st.cplendmant;
-                    bd.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { bd.rv_exp[i] = (uint8_t)((rv_exp >> (4 * i)) & 7u); bd.rv_bap[i] = (uint8_t)((rv_bap >> (4 * i)) & 7u); }
+                    // the descriptor, straight from the lanes (BlkDesc's layout)
+                    {
+                        uint8_t *dp = reinterpret_cast<uint8_t *>(P.desc + (fidx * 6 + blk));
+                        const uint32_t fl = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg << 24);
+                        const uint32_t w0 = lane == 0 ? rd.pos() : lane == 1 ? frame_draws : lane == 2 ? fl : st.cplbndstrc;
+                        if (lane < 4) reinterpret_cast<uint32_t *>(dp)[lane] = w0;
+                        const int em = lane == 0 ? st.endmant[0] : lane == 1 ? st.endmant[1] : lane == 2 ? st.endmant[2] : lane == 3 ? st.endmant[3]
+                                     : lane == 4 ? st.endmant[4] : lane == 5 ? st.cplstrtmant : st.cplendmant;
+                        if (lane < 7) reinterpret_cast<uint16_t *>(dp + 16)[lane] = (uint16_t)em;
+                        if (lane < 8) { dp[32 + lane] = (uint8_t)rv_exp; dp[40 + lane] = (uint8_t)rv_bap; }
+                        const float gl = lane == 0 ? gain[0] : lane == 1 ? gain[1] : lane == 2 ? gain[2] : lane == 3 ? gain[3] : lane == 4 ? gain[4]
+                                       : (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
+                        if (lane < 6) reinterpret_cast<float *>(dp + 48)[lane] = gl;
+                    }
+                    bd_ok = true;
                 }
-                rd.pos = sb.bit;
+                rd.seek(sb.bit);
                 frame_draws += (uint32_t)sb.draw;
             }
 
@@ -555,8 +576,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
             // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
             if constexpr (PARSE) {
-                if (err) bd.flags = 1u;
-                if (lane == 0) P.desc[fidx * 6 + blk] = bd;
+                if ((err || !bd_ok) && lane == 0) reinterpret_cast<uint32_t *>(P.desc + (fidx * 6 + blk))[2] = 1u;      // flags: the block failed
             }
             if (MODE != 1) {
                 if (err && !PARSE)

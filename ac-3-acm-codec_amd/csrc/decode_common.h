@@ -68,29 +68,30 @@ __device__ __forceinline__ int32_t speek(const FrameBits fr, uint32_t pos, int n
 
 struct Rd {                                   // wave-uniform serial reader
     FrameBits fr;
-    uint32_t pos;
-    // 64-bit window of the bits at `wpos` (scalar registers): one LDS read per ~32 bits instead of one per field
-    uint32_t wpos;
+    // 64-bit window (scalar registers): one LDS read per ~32 bits instead of one per field.  The next bit to read is the
+    // window's top bit, at position end - avail; a field costs two shifts and a subtraction.
+    uint32_t end;
     uint64_t win;
     int avail;
-    __device__ __forceinline__ void prime()
+    __device__ __forceinline__ uint32_t pos() const { return end - (uint32_t)avail; }
+    __device__ __forceinline__ void seek(uint32_t p) { end = p; avail = 0; }
+    __device__ __forceinline__ void refill()
     {
-        uint32_t w = pos >> 5;
+        const uint32_t p = pos();
+        uint32_t w = p >> 5;
         w = w < fr.last ? w : fr.last;
         const uint32_t hi = rfl(fr.w[w]), lo = rfl(fr.w[w + 1]);
-        win = (((uint64_t)hi << 32) | lo) << (pos & 31);
-        avail = 64 - (int)(pos & 31);
-        wpos = pos;
+        win = (((uint64_t)hi << 32) | lo) << (p & 31);
+        avail = 64 - (int)(p & 31);
+        end = p + (uint32_t)avail;
     }
     __device__ __forceinline__ uint32_t get(int n)
     {
         if (n == 0) return 0;
-        if (pos != wpos || avail < n) prime();
+        if (avail < n) refill();
         const uint32_t v = (uint32_t)(win >> (64 - n));
         win <<= n;
         avail -= n;
-        pos += n;
-        wpos = pos;
         return v;
     }
     __device__ __forceinline__ int32_t sget(int n)
@@ -98,6 +99,7 @@ struct Rd {                                   // wave-uniform serial reader
         const uint32_t v = get(n);
         return ((int32_t)(v << (32 - n))) >> (32 - n);
     }
+    __device__ __forceinline__ void skip(uint32_t n) { seek(pos() + n); }
 };
 
 __device__ __forceinline__ float sf_of(int e) { return __int_as_float((127 - 15 - e) << 23); }   // 2^-(15+e)

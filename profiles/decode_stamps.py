@@ -14,7 +14,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 pkg = bench.importlib_pkg()
 dev = torch.device("cuda:0")
 eng = pkg.Engine(0)
-eng.set_decode_mode(1)
+eng.set_decode_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 enc = pkg.EncodeDesc(48000, 384000, 6)
 fb = enc.frame_bytes()
 g = torch.Generator(device=dev).manual_seed(99)
