@@ -88,6 +88,12 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
     for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
     for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
 
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int ba_lo0, ba_hi0;                 // the lane's wide band (ba_wide_psd)
+    ba_lane_band(L, lane, ba_lo0, ba_hi0);
+
     St st;
     st.fscod = st.halfrate = st.acmod = st.lfeon = 0;
     st.nf = 0;
@@ -392,50 +398,47 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     if (allzero) {
                         for (int i = lane; i < ROWS; i += 64) L.bap[i] = 0;
                     } else {
-                        // channel slots in turn (wave-uniform), each allocated by the whole wavefront
-                        for (int slot = 0; slot < 7; slot++) {
-                            bool act = false;
-                            int start = 0, end = 0, bndstart = 0, mybai = 0, mydeltbae = 2, fl0 = 0, sl0 = 0;
-                            if (slot < 5) {
-                                act = slot < nf && (redo & (1 << slot));
-                                end = slot == 0 ? st.endmant[0] : slot == 1 ? st.endmant[1] : slot == 2 ? st.endmant[2]
-                                    : slot == 3 ? st.endmant[3] : st.endmant[4];
-                                mybai = slot == 0 ? st.cbai[0] : slot == 1 ? st.cbai[1] : slot == 2 ? st.cbai[2]
-                                      : slot == 3 ? st.cbai[3] : st.cbai[4];
-                                mydeltbae = slot == 0 ? st.deltbae[0] : slot == 1 ? st.deltbae[1] : slot == 2 ? st.deltbae[2]
-                                          : slot == 3 ? st.deltbae[3] : st.deltbae[4];
-                            } else if (slot == 5) {
-                                act = st.lfeon && (redo & 32);
-                                end = 7;
-                                mybai = st.cbai[5];
-                                mydeltbae = 2;
-                            } else {
-                                act = st.chincpl && (redo & 64);
-                                start = st.cplstrtmant;
-                                end = st.cplendmant;
-                                bndstart = st.cplstrtbnd;
-                                mybai = st.cbai[6];
-                                mydeltbae = st.deltbae[5];
-                                fl0 = st.cplfleak << 8;
-                                sl0 = st.cplsleak << 8;
+                        // the channel slots that need a new allocation, two per sweep of the band PSDs (wave-uniform; written
+                        // out rather than as lambdas over `st`: a closure that holds its address keeps the whole state in scratch)
+#define AC3MI_SLOT_END(slot) ((slot) == 0 ? st.endmant[0] : (slot) == 1 ? st.endmant[1] : (slot) == 2 ? st.endmant[2] : (slot) == 3 ? st.endmant[3] \
+                              : (slot) == 4 ? st.endmant[4] : (slot) == 5 ? 7 : st.cplendmant)
+                        int todo = redo & (((1 << nf) - 1) | (st.lfeon ? 32 : 0) | (st.chincpl ? 64 : 0));
+#pragma unroll
+                        for (int i = 0; i < 5; i++) if (st.endmant[i] <= 0) todo &= ~(1 << i);
+                        if (st.cplendmant <= st.cplstrtmant) todo &= ~64;
+                        while (todo) {
+                            const int sA = __builtin_ctz(todo);
+                            todo &= todo - 1;
+                            const bool two = todo != 0;
+                            const int sB = two ? __builtin_ctz(todo) : sA;
+                            if (two) todo &= todo - 1;
+                            const int stA = sA == 6 ? st.cplstrtmant : 0, stB = sB == 6 ? st.cplstrtmant : 0;
+                            const int enA = AC3MI_SLOT_END(sA), enB = AC3MI_SLOT_END(sB);
+                            const int wide = ba_wide_psd(L, ba_lo0, ba_hi0, L.exp + row_off(sA), stA, enA, L.exp + row_off(sB), stB, enB, two, lane);
+                            for (int h = 0; h < (two ? 2 : 1); h++) {          // (one call site: the routine is inlined once)
+                                const int slot = h ? sB : sA, start = h ? stB : stA, end = h ? enB : enA;
+                                const int mybai = slot == 0 ? st.cbai[0] : slot == 1 ? st.cbai[1] : slot == 2 ? st.cbai[2] : slot == 3 ? st.cbai[3]
+                                                : slot == 4 ? st.cbai[4] : slot == 5 ? st.cbai[5] : st.cbai[6];
+                                const int mydeltbae = slot == 0 ? st.deltbae[0] : slot == 1 ? st.deltbae[1] : slot == 2 ? st.deltbae[2] : slot == 3 ? st.deltbae[3]
+                                                    : slot == 4 ? st.deltbae[4] : slot == 5 ? 2 : st.deltbae[5];
+                                BaCtx c;
+                                c.halfrate = st.halfrate;
+                                c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
+                                c.fgain = 128 + 128 * (mybai & 7);
+                                c.sdecay = (15 + 2 * (st.bai >> 9)) >> c.halfrate;
+                                c.sgain = k_slowgain[(st.bai >> 5) & 3];
+                                c.dbknee = k_dbpb[(st.bai >> 3) & 3];
+                                c.hth = L.hth;
+                                c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[slot == 6 ? 5 : slot];
+                                const int fl = k_floors[st.bai & 7];
+                                c.snroffset = 960 - 64 * st.csnroffst - 4 * (mybai >> 3) + fl;
+                                c.floor = fl >> 5;
+                                c.fast = slot == 6 ? st.cplfleak << 8 : 0;
+                                c.slow = slot == 6 ? st.cplsleak << 8 : 0;
+                                bit_allocate_finish(L, L.bmask, c, slot == 6 ? st.cplstrtbnd : 0, start, end, L.exp + row_off(slot), L.bap + row_off(slot), wide, h, lane);
                             }
-                            if (!(act && end > start)) continue;
-                            BaCtx c;
-                            c.halfrate = st.halfrate;
-                            c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
-                            c.fgain = 128 + 128 * (mybai & 7);
-                            c.sdecay = (15 + 2 * (st.bai >> 9)) >> c.halfrate;
-                            c.sgain = k_slowgain[(st.bai >> 5) & 3];
-                            c.dbknee = k_dbpb[(st.bai >> 3) & 3];
-                            c.hth = L.hth;
-                            c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[slot == 6 ? 5 : slot];
-                            const int fl = k_floors[st.bai & 7];
-                            c.snroffset = 960 - 64 * st.csnroffst - 4 * (mybai >> 3) + fl;
-                            c.floor = fl >> 5;
-                            c.fast = fl0;
-                            c.slow = sl0;
-                            bit_allocate_wave(L, L.bmask, c, bndstart, start, end, L.exp + row_off(slot), L.bap + row_off(slot), lane);
                         }
+#undef AC3MI_SLOT_END
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

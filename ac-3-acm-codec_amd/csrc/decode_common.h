@@ -385,6 +385,122 @@ __device__ void bit_allocate_wave(const LDS &L, int16_t *bmask, const BaCtx &c, 
 }
 
 // ---------------------------------------------------------------------------
+// The same allocation with the band PSDs of TWO rows integrated in one sweep (decode.hip): only the 22 bands above bin 27
+// are wider than a bin, so lanes 0-31 take the wide bands of one row and lanes 32-63 those of another.  A band's exponents
+// are fetched once (seven dwords, shifted so that byte 0 is its first bin): the sweep's only dependent LDS access per step
+// is the log-add table.  psd' = min(psd, next) + la_neg[min(|next - psd| >> 1, 255)] is bit_allocate.c:236-251's four
+// cases in one expression (la_neg[255] = 0).
+
+// bins of the wide band 28 + (lane & 31) (0, 0 for lanes without one): constant per lane, computed once per kernel
+template <class LDS>
+__device__ __forceinline__ void ba_lane_band(const LDS &L, int lane, int &lo0, int &hi0)
+{
+    const int t = lane & 31;
+    lo0 = t < 22 ? (int)L.band_end[t + 7] : 0;
+    hi0 = t < 22 ? (int)L.band_end[t + 8] : 0;
+}
+
+template <class LDS>
+__device__ __forceinline__ int ba_wide_psd(const LDS &L, int lo0, int hi0, const uint8_t *eA, int startA, int endA,
+                                           const uint8_t *eB, int startB, int endB, bool two, int lane)
+{
+    const bool upper = lane >= 32;
+    const uint8_t *e = upper ? eB : eA;
+    const int start = upper ? startB : startA, end = upper ? endB : endA;
+    const bool on = (lane & 31) < 22 && (!upper || two);
+    int lo = lo0 > start ? lo0 : start;
+    const int hi = hi0 < end ? hi0 : end;
+    int w = on ? hi - lo : 0;
+    w = w > 0 ? w : 0;
+    lo = w > 0 ? lo : start;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(e + (lo & ~3));
+    uint32_t d[7], a[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) d[i] = q[i];
+    const uint32_t sh = (uint32_t)lo & 3u;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+    int psd = (int)(a[0] & 0xffu) << 7;
+    auto step = [&](int j) __attribute__((always_inline)) {
+        const int next = (int)((a[j >> 2] >> (8 * (j & 3))) & 0xffu) << 7;
+        const int diff = next - psd;
+        int idx = (diff < 0 ? -diff : diff) >> 1;
+        idx = idx > 255 ? 255 : idx;
+        const int nv = (next < psd ? next : psd) + L.la_neg[idx];
+        psd = j < w ? nv : psd;
+    };
+    // bands are 3, 6, 12 or 24 bins wide (fewer at a channel's edges)
+    if (__any(w > 1)) { step(1); step(2); }
+    if (__any(w > 3)) { step(3); step(4); step(5); }
+    if (__any(w > 6)) {
+#pragma unroll
+        for (int j = 6; j < 12; j++) step(j);
+    }
+    if (__any(w > 12)) {
+#pragma unroll
+        for (int j = 12; j < 24; j++) step(j);
+    }
+    return psd;
+}
+
+// everything after the band PSDs for one row; `wide` = ba_wide_psd's result, this row's in the lanes of half `half`
+template <class LDS>
+__device__ void bit_allocate_finish(const LDS &L, int16_t *bmask, const BaCtx &c, int bndstart, int start, int end, const uint8_t *e,
+                                    int8_t *bap, int wide, int half, int lane)
+{
+    constexpr int INF = 0x3fffffff, NEG = -0x3fffffff;
+    const int b = lane;
+    int lo = b < 21 ? b : (int)L.band_end[b < 50 ? b - 21 : 0];
+    int hi = b < 20 ? b + 1 : (int)L.band_end[b < 50 ? b - 20 : 0];
+    lo = lo > start ? lo : start;
+    hi = hi < end ? hi : end;
+    const int w = b < 50 ? hi - lo : 0;
+    const bool live = w > 0;
+    lo = live ? lo : start;
+    const int pw = __shfl(wide, (b >= 28 ? b - 28 : 0) + 32 * half, 64);
+    const int psd = b >= 28 ? pw : 128 * e[lo];
+    // S2: lowcomp and the extent of the first loop
+    int lc = 0, bA = 0;
+    if (start == 0) {
+        const int eb = e[b < 253 ? b : 0], eb1 = e[b < 252 ? b + 1 : 0], ebm = e[b > 0 && b < 254 ? b - 1 : 0];
+        const bool upd = b < 20 && (b >= 7 || b < end - 1);
+        const bool reset = upd && eb1 == eb - 2;
+        const int dec = upd && !reset && eb1 > eb ? 1 : 0;
+        const int D = (int)wave_incl_scan_u32((uint32_t)dec);
+        const int rix = wave_incl_scan_max(reset ? b : NEG);
+        const int Dr = __shfl(D, rix < 0 ? 0 : rix, 64);
+        if (rix >= 0) { lc = (rix < 7 ? 384 : 320) - 64 * (D - Dr); lc = lc < 0 ? 0 : lc; }
+        const int l19 = __builtin_amdgcn_readlane(lc, 19);
+        lc = b == 20 ? (l19 > 128 ? l19 - 128 : 0) : b == 21 ? (l19 > 256 ? l19 - 256 : 0) : b >= 22 ? 0 : lc;
+        const unsigned long long stopm = __ballot(b >= 3 && b < 7 && !(eb > ebm));
+        bA = stopm ? __builtin_ctzll(stopm) : 7;
+    }
+    // S3: leaks
+    const int seed = start == 0 ? bA - 1 : bndstart;
+    const bool in = live && b >= seed;
+    int fast = wave_incl_scan_min(in ? psd + c.fgain - b * c.fdecay : INF) + b * c.fdecay;
+    int slow = wave_incl_scan_min(in ? psd + c.sgain - b * c.sdecay : INF) + b * c.sdecay;
+    if (start != 0) {
+        const int ff = c.fast + (b - bndstart + 1) * c.fdecay, sl = c.slow + (b - bndstart + 1) * c.sdecay;
+        fast = ff < fast ? ff : fast;
+        slow = sl < slow ? sl : slow;
+    }
+    // S4: mask
+    int mask = (start == 0 && b < bA) ? psd + c.fgain + lc : (fast + lc < slow ? fast + lc : slow);
+    if (live) bmask[b] = (int16_t)ba_mask(c, mask, psd, b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // S5: bins
+    const int shift = bndstart - (int)L.band_of_bin[start];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bin = 64 * k + lane;
+        if (bin >= start && bin < end) bap[bin] = ba_width(L.width, (int)bmask[L.band_of_bin[bin] + shift] + 4 * e[bin]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // mantissa helpers
 
 __device__ __forceinline__ int16_t dither_at(const uint16_t *lfsr_seq, uint32_t idx0, int k)
