@@ -121,6 +121,9 @@ struct DecodeLaunch {
     uint8_t *ws_rows = nullptr;     // [S][F][6][7][512]
     float *ws_cplco = nullptr;      // [S][F][6][90]
     uint32_t *ws_fpos = nullptr;    // [S][F]
+    // optional: the mantissa kernel goes to this stream (it waits there for ev_parsed, recorded after the parse kernel)
+    hipStream_t mant_stream = nullptr;
+    hipEvent_t ev_parsed = nullptr;
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 // decode_wg.hip: one workgroup per stream; X == nullptr: coefficient planes (+ taps) to HBM as launch_decode does;
@@ -168,6 +171,10 @@ struct ac3mi_ctx {
     // second stream for the transform of a large decode batch: it overlaps the next chunk's front end
     hipStream_t stream2;
     hipEvent_t ev_chunk[4], ev_mid[4], ev_join;
+    // third stage of the split decode front end: mantissa kernels
+    hipStream_t stream3;
+    hipEvent_t ev_parse[4];
+    int split_chunks;
     ac3mi::DeviceTables tab;
     // decode workspace (coefficient planes + block-switch flags between the two kernels)
     float *ws_coef;

@@ -399,6 +399,8 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_parse[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_mid[i], hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -460,6 +462,11 @@ ac3mi_ctx *ac3mi_create(int device)
         if (m >= 0 && m <= 5) ctx->decode_mode = m;
     }
     ctx->tile_frames = 131072;
+    ctx->split_chunks = 2;
+    if (const char *e = getenv("AC3MI_SPLIT_CHUNKS")) {         // profiling aid: chunks of the three-stage decode pipeline
+        const int m = atoi(e);
+        if (m >= 1 && m <= 4) ctx->split_chunks = m;
+    }
     ctx->no_overlap = getenv("AC3MI_NO_OVERLAP") != nullptr;     // profiling aid: one chunk, one stream, kernels back to back
     ctx->ws_draws = nullptr;
     ctx->ws_draws_bytes = 0;
@@ -501,6 +508,8 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_chunk[i]);
     for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_mid[i]);
     (void)hipEventDestroy(ctx->ev_join);
+    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_parse[i]);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -976,7 +985,10 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     }
     // A large batch goes through in two chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 5.06 / 4.93 / 4.94 / 5.04 ms (4 was best before the front end ran 6 waves/SIMD)
+    // (one-kernel front end, measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 5.06 / 4.93 / 4.94 / 5.04 ms.)  The split front end
+    // adds a stage: parse kernel (scalar-unit-bound) of chunk k+1 on stream 1, mantissa kernel (vector-bound) of chunk k on
+    // stream 3, transform (HBM-bound) of chunk k-1 on stream 2.
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? (split ? ctx->split_chunks : 2) : 1;
     const size_t F = (size_t)frames_per_stream;
     for (int k = 0; k < n_chunks; k++) {
         const int s0 = (int)((long long)n_streams * k / n_chunks), s1 = (int)((long long)n_streams * (k + 1) / n_chunks);
@@ -1012,11 +1024,13 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
         }
+        hipStream_t fs = ctx->stream;                       // where the front end of the chunk ends
+        if (split && n_chunks > 1) { D.mant_stream = ctx->stream3; D.ev_parsed = ctx->ev_parse[k]; fs = ctx->stream3; }
         HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
 
         hipStream_t xs = ctx->stream;
         if (n_chunks > 1) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_chunk[k], ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_chunk[k], fs));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_chunk[k], 0));
             xs = ctx->stream2;
         }
@@ -1300,7 +1314,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
     // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? 2 : 1;       // measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
+    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? (split ? ctx->split_chunks : 2) : 1;       // (one-kernel front end) measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
@@ -1331,6 +1345,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
             const SplitWs w = split_ws(ctx, nfr, f0);
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
+            if (n_chunks > 1) { D.mant_stream = ctx->stream3; D.ev_parsed = ctx->ev_parse[k]; }
         }
         if (fused) {
             XformLaunch Y = X;
@@ -1405,7 +1420,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     hipEvent_t *ev = ctx->ev_chunk;                     // front end of chunk k done
     for (int k = 0; k < n_chunks; k++) {
         HIPCHK(ctx, front(k));
-        HIPCHK(ctx, hipEventRecord(ev[k], ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ev[k], split ? ctx->stream3 : ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ev[k], 0));
         HIPCHK(ctx, middle(k, ctx->stream2));
         HIPCHK(ctx, hipEventRecord(ctx->ev_mid[k], ctx->stream2));

@@ -653,7 +653,7 @@ struct MantLDS {
 };
 
 #ifndef MANT_LB
-#define MANT_LB 6
+#define MANT_LB 8
 #endif
 __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
 {
@@ -689,17 +689,30 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
         if (tid < M2_NDESC) L.dsc[tid] = mant_desc2((uint32_t)tid);
         for (int i = tid; i < 760; i += 384) L.qtab[i] = P.tab->qtab[i];
     }
-    __syncthreads();
     float *cblk = P.coef + unit * P.n_in * 256;
     const uint32_t flags = rfl(w0v.z);
-    if (flags & 1u) {                                           // a failed block leaves zero planes
+    const bool failed = (flags & 1u) != 0u;
+    MantBlk B;
+    B.nf = P.nfchans; B.lfeon = P.lfeon; B.acmod = P.acmod; B.in_lfe = P.lfeon ? 1 : 0;
+    B.chincpl = (int)((flags >> 8) & 31u); B.dithmask = (int)((flags >> 16) & 31u); B.rematflg = (int)((flags >> 24) & 15u);
+    const uint64_t rve = (uint64_t)rfl(w2v.x) | ((uint64_t)rfl(w2v.y) << 32), rvb = (uint64_t)rfl(w2v.z) | ((uint64_t)rfl(w2v.w) << 32);
+    const uint8_t *rowbase = P.rows + (size_t)fidx * 6 * ROWSET;
+    auto fetch = [&](int slot) -> uint2 {
+        const uint8_t *er = rowbase + (size_t)((rve >> (8 * slot)) & 7u) * ROWSET + slot * 512;
+        const uint8_t *br = rowbase + (size_t)((rvb >> (8 * slot)) & 7u) * ROWSET + slot * 512 + 256;
+        if (slot == 5) return lane < 7 ? make_uint2(br[lane], er[lane]) : make_uint2(1u, 0u);
+        return make_uint2(reinterpret_cast<const uint32_t *>(br)[lane], reinterpret_cast<const uint32_t *>(er)[lane]);
+    };
+    // the first segment's rows are requested before the workgroup meets at the barrier
+    const int slot0 = seg_slot(0, B.nf, B.chincpl, B.chincpl ? __builtin_ctz(B.chincpl) : 99);
+    uint2 first = make_uint2(0u, 0u);
+    if (!failed) first = fetch(slot0);
+    __syncthreads();
+    if (failed) {                                               // a failed block leaves zero planes
         for (int c = 0; c < P.n_in; c++)
             *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    MantBlk B;
-    B.nf = P.nfchans; B.lfeon = P.lfeon; B.acmod = P.acmod; B.in_lfe = P.lfeon ? 1 : 0;
-    B.chincpl = (int)((flags >> 8) & 31u); B.dithmask = (int)((flags >> 16) & 31u); B.rematflg = (int)((flags >> 24) & 15u);
     {
         const uint32_t a = rfl(w1v.x), b = rfl(w1v.y), c = rfl(w1v.z), d = rfl(w1v.w);
         B.endmant[0] = (int)(a & 0xffffu); B.endmant[1] = (int)(a >> 16); B.endmant[2] = (int)(b & 0xffffu); B.endmant[3] = (int)(b >> 16);
@@ -714,16 +727,8 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
     const uint32_t fpos = rfl(fposv);
     const bool lfsr_live = fpos != 0xffffffffu;
     const uint32_t i0 = lfsr_live ? (fpos + rfl(w0v.y)) % 65535u : 0u;            // the generator's position before the block's first draw
-    const uint64_t rve = (uint64_t)rfl(w2v.x) | ((uint64_t)rfl(w2v.y) << 32), rvb = (uint64_t)rfl(w2v.z) | ((uint64_t)rfl(w2v.w) << 32);
-    const uint8_t *rowbase = P.rows + (size_t)fidx * 6 * ROWSET;
     const float *cc = P.cplco + unit * 90;
-    auto fetch = [&](int slot) -> uint2 {
-        const uint8_t *er = rowbase + (size_t)((rve >> (8 * slot)) & 7u) * ROWSET + slot * 512;
-        const uint8_t *br = rowbase + (size_t)((rvb >> (8 * slot)) & 7u) * ROWSET + slot * 512 + 256;
-        if (slot == 5) return lane < 7 ? make_uint2(br[lane], er[lane]) : make_uint2(1u, 0u);
-        return make_uint2(reinterpret_cast<const uint32_t *>(br)[lane], reinterpret_cast<const uint32_t *>(er)[lane]);
-    };
-    mant_block2(B, fetch, [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.dsc, L.ring[blk], frw, (uint32_t)nw + 2u,
+    mant_block2(B, fetch, first, [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.dsc, L.ring[blk], frw, (uint32_t)nw + 2u,
                 L.qtab, reinterpret_cast<const int16_t *>(P.lfsr_seq) + 1 + i0, lfsr_live, cblk, rfl(w0v.x), lane);
 }
 
@@ -809,7 +814,15 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
         M.lfeon = L.lfeon;
         M.n_in = P.n_in;
         M.nfchans = P.nfchans;
-        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, stream, M);
+        hipStream_t ms = stream;
+        if (L.mant_stream && L.mant_stream != stream) {
+            hipError_t e = hipEventRecord(L.ev_parsed, stream);
+            if (e != hipSuccess) return e;
+            e = hipStreamWaitEvent(L.mant_stream, L.ev_parsed, 0);
+            if (e != hipSuccess) return e;
+            ms = L.mant_stream;
+        }
+        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, ms, M);
         return hipGetLastError();
     }
     if (!L.frame_parallel) {

@@ -143,7 +143,7 @@ __device__ __forceinline__ float dither2(const int16_t *seq, uint32_t i) { retur
 // one dword each (bins 4 lane .. 4 lane + 3), for the LFE (slot 5) one byte each (bin = lane, lanes 0..6).
 // seq1 = lfsr_seq + 1 + the generator's position before the block's first draw (draw k is seq1[k]).
 template <class Fetch, class Cplco>
-__device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, Cplco cplco_of, const uint8_t *cplbnd, const uint4 *dsc, uint8_t *ring,
+__device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2 first, Cplco cplco_of, const uint8_t *cplbnd, const uint4 *dsc, uint8_t *ring,
                                             const uint32_t *frw, uint32_t frw_last, const float *qtab, const int16_t *seq1, bool lfsr_live,
                                             float *cblk, uint32_t bitpos, int lane)
 {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, Cplco
     S.bit = bitpos;
     S.phase = 0;
     S.draw = 0;
-    uint2 nxt = fetch(seg_slot(0, nf, B.chincpl, cplfirst));
+    uint2 nxt = first;                  // = fetch(slot of segment 0), requested by the caller
     for (int k = 0; k < nseg; k++) {
         const int slot = seg_slot(k, nf, B.chincpl, cplfirst);
         const uint2 cur = nxt;
