@@ -559,6 +559,13 @@ int ac3mi_memset(ac3mi_ctx *ctx, void *d_dst, int byte, size_t bytes)
     return AC3MI_OK;
 }
 
+int ac3mi_memcpy_d2d(ac3mi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx) return AC3MI_ERR_ARG;
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return AC3MI_OK;
+}
+
 int ac3mi_sync(ac3mi_ctx *ctx)
 {
     if (!ctx) return AC3MI_ERR_ARG;

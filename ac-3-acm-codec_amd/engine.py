@@ -99,6 +99,16 @@ class Engine:
         self._check(self.lib.ac3mi_sync(self.ctx))
         self._keep.clear()
 
+    def memset(self, t, byte=0):
+        """ac3mi_memset of a whole tensor on the engine's stream (asynchronous)."""
+        self._check(self.lib.ac3mi_memset(ctypes.c_void_p(self.ctx), ctypes.c_void_p(t.data_ptr()), int(byte), ctypes.c_size_t(t.numel() * t.element_size())))
+
+    def copy(self, dst, src):
+        """ac3mi_memcpy_d2d of a whole tensor on the engine's stream (asynchronous)."""
+        assert dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        self._check(self.lib.ac3mi_memcpy_d2d(ctypes.c_void_p(self.ctx), ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()),
+                                              ctypes.c_size_t(dst.numel() * dst.element_size())))
+
     def timer_start(self):
         self._check(self.lib.ac3mi_timer_start(self.ctx))
 
@@ -230,7 +240,8 @@ class Engine:
 
     def set_decode_mode(self, mode):
         """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame, 3 = one workgroup per stream
-        with the transform fused in (ac3mi_set_decode_mode)."""
+        with the transform fused in, 4 / 5 = parse kernel per stream / per frame + one wavefront per audio block
+        (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
     def set_mix_state(self, pending=None, flags=None):

@@ -65,6 +65,9 @@ void ac3mi_dev_free(ac3mi_ctx *ctx, void *d_ptr);
 int ac3mi_memcpy_h2d(ac3mi_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ac3mi_memcpy_d2h(ac3mi_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int ac3mi_memset(ac3mi_ctx *ctx, void *d_dst, int byte, size_t bytes);
+/* device-to-device copy on the context's stream (asynchronous like the batch calls): e.g. stream state back to its
+ * initial values between benchmark passes */
+int ac3mi_memcpy_d2d(ac3mi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 /* All engine calls are asynchronous on the context's own HIP stream. */
 int ac3mi_sync(ac3mi_ctx *ctx);
 
@@ -136,12 +139,17 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
  *   3  one 512-thread workgroup per stream: a wavefront per channel beside a parser and a transformer wavefront, the
  *      coefficient planes stay in LDS and the transform is fused in (a third of the latency of variant 1 per frame,
  *      no plane traffic in HBM; ahead for batches of up to about 1 500 streams);
- *   0  (default) choose by batch shape.
+ *   4  the split front end, parse kernel per stream: one wavefront per stream parses side information, decodes
+ *      exponents and allocates bits, frames in order, and only COUNTS each block's mantissas (from per-row totals); it
+ *      leaves a descriptor per audio block plus the exponent / allocation rows that changed, and a second kernel unpacks
+ *      and dequantises every block with a wavefront of its own (six per frame), before the transform kernel;
+ *   5  the same with the parse kernel per frame and variant 2's prefix pass over the dither draws (few, long streams);
+ *   0  (default) choose by batch shape: 3 for up to 1 024 streams of at most four frames, else 4 or 5.
  * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
  * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and
  * the fused and the separate transform execute the same arithmetic.  A frame whose block 0 reuses state it did not send
- * (damaged or non-conforming) gets status bit AC3MI_STATUS_REUSE0 (0x200): variants 1 and 3 then continue from what the
- * previous frame of the call left behind (as liba52 does), variant 2 from zeros - the result depends on the batch shape. */
+ * (damaged or non-conforming) gets status bit AC3MI_STATUS_REUSE0 (0x200): variants 1, 3 and 4 then continue from what the
+ * previous frame of the call left behind (as liba52 does), variants 2 and 5 from zeros - the result depends on the batch shape. */
 #define AC3MI_STATUS_REUSE0 0x200u
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 

@@ -34,6 +34,23 @@ typedef float sample_t;
 typedef float level_t;
 typedef struct a52_state_s a52_state_t;
 
+/* the flags word of a52_syncinfo / a52_frame: a52dec-0.7.5-cvs/include/a52.h:40-54 */
+#define A52_CHANNEL 0
+#define A52_MONO 1
+#define A52_STEREO 2
+#define A52_3F 3
+#define A52_2F1R 4
+#define A52_3F1R 5
+#define A52_2F2R 6
+#define A52_3F2R 7
+#define A52_CHANNEL1 8
+#define A52_CHANNEL2 9
+#define A52_DOLBY 10
+#define A52_CHANNEL_MASK 15
+
+#define A52_LFE 16
+#define A52_ADJUST_LEVEL 32
+
 a52_state_t *a52_init(uint32_t mm_accel);
 sample_t *a52_samples(a52_state_t *state);
 int a52_syncinfo(uint8_t *buf, int *flags, int *sample_rate, int *bit_rate);
@@ -42,7 +59,10 @@ void a52_dynrng(a52_state_t *state, level_t (*call)(level_t, void *), void *data
 int a52_block(a52_state_t *state);
 void a52_free(a52_state_t *state);
 
-/* extern "C" aliases of the encoder entry points (the C++-mangled ones are exported too) */
+/* extern "C" aliases of the encoder entry points.  The library also exports them under the C++ names the reference's
+ * own translation units link against (src/ac3enc/ac3enc.h:6-7 is included without extern "C" by src/AC3ACM.cpp:60):
+ * a C++ host declares `int AC3_encode_init(int freq, int bitrate, int channels); int AC3_encode_frame(unsigned char *dst,
+ * short *samples, unsigned char *chmap);` exactly as that header does and links libac3mi.so (tests/dropin_c/enc_host.cpp). */
 int ac3mi_AC3_encode_init(int freq, int bitrate, int channels);
 int ac3mi_AC3_encode_frame(unsigned char *dst, short *samples, unsigned char *chmap);
 

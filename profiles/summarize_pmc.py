@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of profiles/run_r02.sh into the summaries committed under profiles/:
+"""Turns the rocprofv3 outputs of profiles/run_r03.sh (run_r02.sh) into the summaries committed under profiles/:
    <tag>_kernel_stats.csv      per-kernel durations (kernel trace of the whole bench, secondary legs included)
    <tag>_hbm_traffic.json      per kernel: FETCH_SIZE (doubled, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE per launch vs the
                                algorithmic bytes of SURVEY.md 8(d)
@@ -63,6 +63,8 @@ ALG = {
     "xform_kernel<true, 2, false>": 30720 + 12288 + 2048,
     "xform_kernel<true, 3, false>": 30720 + 12288 + 2048,
     "decode_kernel<0>": 1536 + 36864,
+    "decode_kernel<4>": 1536 + 480,             # frame in, six block descriptors out (+ the rows that changed: data-dependent)
+    "mant_kernel": 1536 + 480 + 36864,          # frame + descriptors in (+ the rows of every segment), planes out
     "decode_wg_kernel<0>": 1536 + 36864,
     "decode_wg_kernel<1>": 1536 + 36864 + 6144,
     "decode_wg_kernel<2>": 1536 + 18432 + 6144,
@@ -109,8 +111,8 @@ def pick(*prefixes):
 
 
 legs = {
-    "decode": pick("decode_kernel<0>", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
-    "decode_s16": pick("decode_kernel<0>", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
+    "decode": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
+    "decode_s16": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
     "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>"),
     "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>", "xform_kernel<true, 3, false>"),
 }

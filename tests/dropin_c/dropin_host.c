@@ -14,9 +14,6 @@
 #include <string.h>
 #include "ac3mi_dropin.h"
 
-#define A52_CHANNEL_MASK 15
-#define A52_LFE 16
-
 static int nchans(int flags)
 {
     static const int n[11] = {2, 1, 2, 3, 3, 4, 4, 5, 1, 1, 2};

@@ -35,3 +35,13 @@ def test_under_an_external_launcher_nothing_is_spawned():
     """With WORLD_SIZE in the environment (torch.distributed.run) the script is a rank, not a launcher."""
     d = _run(["--gpus", "2", "--launch-check"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert d["n_gpus"] == 1
+
+
+def test_eight_ranks_plan_the_8m_stream_job():
+    """BASELINE configs[4]: 8M streams over 8 ranks.  Eight gloo ranks (CPU) rendezvous, take their contiguous shards and
+    plan the HBM of their share of the transcode (sharding.plan_transcode_bytes: I/O and per-stream state grow with the
+    shard, the engine's workspaces stop at ac3mi_set_tile_frames' default): every rank fits 288 GB with room to spare."""
+    d = _run(["--gpus", "8", "--launch-check", "--job-streams", str(8 * (1 << 20))])
+    assert d["n_gpus"] == 8 and d["streams_total"] == 8 * (1 << 20)
+    assert d["ranks_that_fit_288GB"] == 8
+    assert 20e9 < d["max_rank_hbm_plan_bytes"] < 60e9

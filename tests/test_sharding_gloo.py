@@ -72,3 +72,15 @@ def test_two_ranks_gloo():
     coef = (rng.standard_normal((n_streams, 1, 6, 6, 256)) * 0.05).astype(np.float32)
     pcm, _ = H.orc_xform(coef, None, 7, 1, 7 | 16)
     assert abs(sum(r[5] for r in res) - float(np.abs(pcm).sum())) < 1e-3
+
+
+def test_rank_plan_fits_hbm():
+    """What one rank plans for its shard (sharding.plan_transcode_bytes): the workspaces stop growing at the tile bound,
+    so BASELINE configs[4]'s per-GPU share (2^20 streams) needs ~30 GB, and a rank could hold about 25 M one-frame streams."""
+    sh = H.pkg().sharding
+    lo, hi = sh.shard(8 * (1 << 20), 8, 5)
+    p = sh.plan_transcode_bytes(hi - lo)
+    assert p["fits"] and 20e9 < p["total"] < 60e9
+    assert p["workspace"] == sh.plan_transcode_bytes(1 << 24)["workspace"]           # bounded by the tile
+    assert sh.plan_transcode_bytes(4096)["workspace"] < p["workspace"]                # small batches: only what they use
+    assert not sh.plan_transcode_bytes(40_000_000)["fits"]
