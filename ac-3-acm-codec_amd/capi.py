@@ -89,6 +89,7 @@ def load_library():
     lib.ac3mi_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.ac3mi_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.ac3mi_memset.argtypes = [c_void_p, c_void_p, c_int, c_size_t]
+    lib.ac3mi_set_encode_mode.argtypes = [c_void_p, c_int]
     lib.ac3mi_memcpy_d2d.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t]
     lib.ac3mi_sync.argtypes = [c_void_p]
     lib.ac3mi_timer_start.argtypes = [c_void_p]

@@ -151,6 +151,7 @@ struct EncodeLaunch {
     uint8_t *tap_eexp, *tap_bap, *tap_strat;
     int32_t *tap_snr;
     const int32_t *slot;
+    int pack_mode = 0;          // ac3mi_set_encode_mode
 };
 hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStream_t stream);
 hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream);
@@ -175,6 +176,7 @@ struct ac3mi_ctx {
     hipStream_t stream3;
     hipEvent_t ev_parse[4];
     int split_chunks;
+    int encode_mode;        // ac3mi_set_encode_mode
     ac3mi::DeviceTables tab;
     // decode workspace (coefficient planes + block-switch flags between the two kernels)
     float *ws_coef;

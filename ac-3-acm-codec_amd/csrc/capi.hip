@@ -462,6 +462,11 @@ ac3mi_ctx *ac3mi_create(int device)
         if (m >= 0 && m <= 5) ctx->decode_mode = m;
     }
     ctx->tile_frames = 131072;
+    ctx->encode_mode = 0;
+    if (const char *e = getenv("AC3MI_ENCODE_MODE")) {          // test aid: default packer variant (ac3mi_set_encode_mode)
+        const int m = atoi(e);
+        if (m >= 0 && m <= 2) ctx->encode_mode = m;
+    }
     ctx->split_chunks = 2;
     if (const char *e = getenv("AC3MI_SPLIT_CHUNKS")) {         // profiling aid: chunks of the three-stage decode pipeline
         const int m = atoi(e);
@@ -685,6 +690,13 @@ int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 5) return AC3MI_ERR_ARG;
     ctx->decode_mode = mode;
+    return AC3MI_OK;
+}
+
+int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return AC3MI_ERR_ARG;
+    ctx->encode_mode = mode;
     return AC3MI_OK;
 }
 
@@ -1211,6 +1223,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     E.last = d_last;
     E.csnr = d_csnroffst;
     E.slot = ctx->slots;
+    E.pack_mode = ctx->encode_mode;
     E.frames = d_frames;
     E.frame_stride = frame_stride;
     E.n_streams = n_streams;
@@ -1249,6 +1262,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         return AC3MI_ERR_ARG;
     }
     EncodeLaunch E;
+    E.pack_mode = ctx->encode_mode;
     const int fb = enc_config(enc->sample_rate, enc->bit_rate, enc->channels, &E.cfg);
     if (fb <= 0 || enc->channels != n_out) {
         ctx->err = "ac3mi_transcode_batch: encoder configuration rejected, or its channel count differs from the decoder's output";

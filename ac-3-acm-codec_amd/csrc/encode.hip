@@ -832,7 +832,8 @@ __device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :116
 
 // CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
 // bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
-__device__ uint32_t region_crc(const PackLDS &L, const uint32_t *fr, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
+template <class LDS>
+__device__ uint32_t region_crc(const LDS &L, const uint32_t *fr, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
 {
     const int start = end - 64 * C;                 // may be negative: leading zero padding
     int p = start + lane * C;
@@ -1471,6 +1472,388 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
     PK_END();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// enc_packb_kernel: a frame whose SNR offsets are known (P.snr, from enc_pack_kernel<1>) is packed by a workgroup of six
+// wavefronts, one per AUDIO BLOCK.  Nothing but its first bit ties a block to the blocks before it, and that follows from
+// bit COUNTS: every wavefront first counts its block (side information from the strategies, mantissas from one table look-up
+// per coefficient), the counts meet in LDS, then all six pack at once into the frame they share (fields reach it by LDS
+// atomics, so neighbours may write into one dword); both CRCs run side by side on two wavefronts; 384 lanes store the frame.
+// The reference's merged-code marker quirk (a grouped code whose value equals 128 is not written, :1466-1480) shortens a
+// block, i.e. moves every later block: any wavefront that meets one reports it, and the workgroup packs the frame once more
+// with those fields at width 0 - as enc_pack_kernel does per block.
+
+struct PackbWave {                  // per wavefront = audio block
+    int16_t mask[6][50];            // masking curves of the block's channels, minus the floor
+    uint32_t gtab[640];             // see PackLDS::gtab
+    alignas(4) uint8_t erow[256];
+    uint32_t coll[32];
+    int ncoll;
+};
+struct alignas(16) PackbLDS {
+    PackbWave w[6];
+    uint32_t packlut[64];
+    uint16_t crc_tab[256];
+    uint8_t band_of_bin[256];
+    uint32_t blk_bits[6];
+    uint32_t crc[2];
+    int any_coll;
+};
+
+#ifndef ENC_PACKB_LB
+#define ENC_PACKB_LB 6
+#endif
+__global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const PackParams P)
+{
+    __shared__ PackbLDS L;
+    extern __shared__ uint4 pk_dyn[];
+    uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PackbWave &W = L.w[b];
+    // consecutive frames on one XCD (cdna_hip_programming.md T1): the six wavefronts' rows sit side by side in memory
+    size_t fidx;
+    {
+        const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        fidx = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc, fs = P.frame_words;
+    constexpr int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
+
+    for (int i = tid; i < 256; i += 384) {
+        L.band_of_bin[i] = P.tab->band_of_bin[i];
+        L.crc_tab[i] = P.tab->crc_tab[i];
+    }
+    if (tid < 64) L.packlut[tid] = pack_word(P.tab->baptab[tid]);
+    for (int i = tid; i < P.frw / 4; i += 384) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
+    const size_t rowb = (fidx * 6 + b) * nch;
+    {
+        const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + rowb * 50);
+        for (int i = lane; i < nch * 25; i += 64) {
+            const int row = i / 25, w = i - 25 * row;
+            reinterpret_cast<uint32_t *>(&W.mask[row][0])[w] = gm[i];
+        }
+    }
+    // lane = channel: exponent strategy and exp_samples of the block's channels
+    const int strat_l = lane < nch ? (int)P.strat[rowb + lane] : 0;
+    const int shift_l = lane < nch ? (int)P.shift[rowb + lane] : 0;
+    uint32_t ew[6];                                     // the block's encoded exponents, four bins per lane and channel
+#pragma unroll
+    for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(P.eexp + (rowb + ch) * 256 + 4 * lane) : 0u;
+    const int32_t *mdb = P.mdct + rowb * 256;
+    int csnr, fsnr, snroffset;
+    {
+        const int w1 = P.snr[fidx * 2 + 1];
+        csnr = P.snr[fidx * 2];
+        fsnr = w1 & 15;
+        snroffset = (((csnr - 15) << 4) + fsnr) << 2;
+        if (w1 & 0x100) snroffset = (((w1 >> 9) - 15) << 4) << 2;      // a frame whose search failed: see enc_pack_kernel
+    }
+    if (lane == 0) W.ncoll = 0;
+    if (tid == 0) L.any_coll = 0;
+    const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&P.tab->band_of_bin[4 * lane]);
+    __syncthreads();
+
+    const uint32_t strat_set = (uint32_t)__ballot(strat_l != 0);        // bit ch: the channel sends exponents in this block
+    auto strat_of = [&](int ch) { return __builtin_amdgcn_readlane(strat_l, ch); };
+    // bits of the frame header (:1113-1147) and of this block's side information with its exponents (:1194-1332)
+    const int hdr_bits = 16 + 16 + 2 + 6 + 5 + 3 + 3 + (((P.acmod & 1) && P.acmod != 1) ? 2 : 0) + ((P.acmod & 4) ? 2 : 0) +
+                         (P.acmod == 2 ? 2 : 0) + 1 + 5 + 3 + 1 + 1 + 3;
+    int side_bits = 2 * nfbw + 1 + (b == 0 ? 2 : 1) + (P.acmod == 2 ? (b == 0 ? 5 : 1) : 0) + 2 * nfbw + (P.lfe ? 1 : 0) +
+                    1 + (b == 0 ? 11 : 0) + 1 + (b == 0 ? 6 + 7 * nch : 0) + 2;
+    for (int ch = 0; ch < nch; ch++) {
+        const int stg = strat_of(ch);
+        if (stg == 0) continue;
+        const bool is_lfe = P.lfe && ch == nch - 1;
+        const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
+        side_bits += 4 + 7 * (((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs)) + (is_lfe ? 0 : 8);      // (fbw: chbwcod 6 + gainrng 2)
+    }
+
+    // the addresses of the block's coefficients into the bap table (:393-420), four per lane and channel: 6 bits each
+    uint32_t ad[6];
+#pragma unroll
+    for (int ch = 0; ch < 6; ch++) {
+        ad[ch] = 0;
+        if (ch < nch) {
+            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+            const int16_t *Mr = &W.mask[ch][0];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int xe = (int)((ew[ch] >> (8 * j)) & 0xff), m = Mr[(bandoff >> (8 * j)) & 0xff];
+                const int d4 = 4 * lane + j < n ? 320 - 16 * xe : -(1 << 20);
+                ad[ch] |= (uint32_t)lut_index(d4, m, snroffset) << (8 * j);
+            }
+        }
+    }
+
+    int dropped_known = 0;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // ---- this block's bit count -> where it starts ----
+        {
+            uint32_t cnt = 0, plain = 0;            // kinds as 10-bit fields (<= 24 per lane), plain bits
+#pragma unroll
+            for (int ch = 0; ch < 6; ch++) {
+                if (ch >= nch) continue;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t w = L.packlut[(ad[ch] >> (8 * j)) & 63u];
+                    cnt += 1u << (w >> 24);
+                    plain += w & 31u;
+                }
+            }
+            const uint32_t s1 = wave_sum_u32((cnt & 1023u) | (((cnt >> 10) & 1023u) << 16));
+            const uint32_t s2 = wave_sum_u32(((cnt >> 20) & 1023u) | (plain << 16));
+            const int n1 = s1 & 0xffff, n2 = s1 >> 16, n4 = s2 & 0xffff;
+            int bits = side_bits + (int)(s2 >> 16) + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+            for (int q = 0; q < dropped_known; q++) bits -= (W.coll[q] >> 16) == 0 ? 5 : 7;
+            if (lane == 0) L.blk_bits[b] = (uint32_t)bits;
+        }
+        __syncthreads();
+        uint32_t pos = (uint32_t)hdr_bits;
+        for (int q = 0; q < b; q++) pos += L.blk_bits[q];
+
+        // ---- side information (wave-uniform fields through a 64-bit accumulator, see enc_pack_kernel) ----
+        uint64_t acc = 0;
+        int nacc = 0;
+        auto put = [&](int n, uint32_t v) {
+            acc = (acc << n) | v;
+            nacc += n;
+            if (nacc >= 32) {
+                const uint32_t word = (uint32_t)(acc >> (nacc - 32));
+                if (lane == 0) put_bits(fr, P.frw, pos, 32, word);
+                pos += 32;
+                nacc -= 32;
+            }
+        };
+        auto flush = [&]() {
+            if (nacc > 0) {
+                const uint32_t word = (uint32_t)acc & (0xffffffffu >> (32 - nacc));
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc, word);
+                pos += nacc;
+                nacc = 0;
+            }
+        };
+        if (b == 0) {                               // the frame header is block 0's to write
+            const uint32_t mine = pos;
+            pos = 0;
+            put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+            if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
+            if (P.acmod & 4) put(2, 1);
+            if (P.acmod == 2) put(2, 0);
+            put(1, P.lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
+            flush();
+            pos = mine;
+        }
+        for (int ch = 0; ch < nfbw; ch++) put(1, 0);
+        for (int ch = 0; ch < nfbw; ch++) put(1, 1);
+        put(1, 0);
+        if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
+        if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
+        for (int ch = 0; ch < nfbw; ch++) put(2, (uint32_t)strat_of(ch));
+        if (P.lfe) put(1, (uint32_t)strat_of(nch - 1));
+        for (int ch = 0; ch < nfbw; ch++) if ((strat_set >> ch) & 1u) put(6, P.chbwcod);
+        // exponents: lanes over groups
+        for (int ch = 0; ch < nch; ch++) {
+            const int stg = strat_of(ch);
+            if (stg == 0) continue;
+            const bool is_lfe = P.lfe && ch == nch - 1;
+            const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
+            const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
+            const uint8_t *e = &W.erow[0];
+            {
+                uint32_t row = 0;
+#pragma unroll
+                for (int c2 = 0; c2 < 6; c2++) row = c2 == ch ? ew[c2] : row;
+                WAVE_SYNC();                                            // the previous channel's groups have read the row
+                *reinterpret_cast<uint32_t *>(&W.erow[4 * lane]) = row;
+                WAVE_SYNC();
+            }
+            put(4, (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+            flush();
+            for (int g = lane; g < ng; g += 64) {
+                const int k0 = 1 + 3 * g * gs;
+                const int prev = g ? e[k0 - gs] : e[0];
+                const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
+                put_bits(fr, P.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+            }
+            pos += 7 * ng;
+            if (!is_lfe) put(2, 0);
+        }
+        put(1, b == 0);
+        if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
+        put(1, b == 0);
+        if (b == 0) {
+            put(6, (uint32_t)csnr);
+            for (int ch = 0; ch < nch; ch++) { put(4, (uint32_t)fsnr); put(3, fgaincod); }
+        }
+        put(1, 0);
+        put(1, 0);
+        flush();
+
+        // ---- mantissas (:1334-1502): as in enc_pack_kernel, one pass per channel, four coefficients per lane ----
+        {
+            const uint32_t marker = (uint32_t)P.marker;
+            int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
+            uint32_t baseg = 0, basem = 0;
+            int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
+            uint32_t *const sink = &W.gtab[512 + 2 * lane];
+#pragma unroll 1
+            for (int ch = 0; ch < nch; ch++) {
+                const int4 c4 = nx_c;
+                uint32_t e4 = 0, a4 = 0;
+#pragma unroll
+                for (int c2 = 0; c2 < 6; c2++) { e4 = c2 == ch ? ew[c2] : e4; a4 = c2 == ch ? ad[c2] : a4; }
+                {
+                    const int nc = ch + 1 < nch ? ch + 1 : ch;          // the next channel's coefficients are in flight meanwhile
+                    nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
+                }
+                const int shv = __builtin_amdgcn_readlane(shift_l, ch);
+                const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
+                uint32_t pw[4], cnt_lane = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    pw[j] = L.packlut[(a4 >> (8 * j)) & 63u];
+                    cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
+                }
+                if (P.tap_bap)
+                    *reinterpret_cast<uint32_t *>(P.tap_bap + (rowb + ch) * 256 + 4 * lane) =
+                        ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                const uint32_t gin = wave_incl_scan_u32(cnt_lane);
+                uint32_t run = gin - cnt_lane;
+                uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
+                uint32_t bits_lane = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
+                    const uint32_t r = ((run >> sh) & 1023u) + ((basem >> (2 * kind)) & 3u);
+                    run += 1u << sh;
+                    const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
+                    const uint32_t gl = kind < 2 ? by3 : by2;
+                    const uint32_t per = 3u - (kind >> 1);
+                    const uint32_t idx = 4 * kind + (r - gl * per);
+                    const uint32_t opens = (0x0111u >> idx) & 1u, last = (0x0244u >> idx) & 1u, member = (0x0266u >> idx) & 1u;
+                    const uint32_t grp = ((baseg >> (8 * kind)) & 255u) + gl;
+                    const uint32_t ring = 128u * kind + (grp & (127u | ((kind & 2u) << 6)));
+                    slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
+                    const uint32_t gbits = (pw[j] >> 7) & 7u;
+                    nb[j] = w + gbits * opens;
+                    bits_lane += nb[j];
+                    fl[j] = opens | (last << 1) | (member << 2) | (gbits << 4) | (gl << 8);
+                    const int levels = (int)((pw[j] >> 10) & 15u);
+                    const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
+                    const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
+                    const int q = ((pw[j] >> 14) & 1u) ? vs : va;
+                    const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
+                    vq[j] = (uint32_t)q & 0xffffu;
+                    vw[j] = (uint32_t)(q * wgt) << 16;
+                }
+                if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t kind = (pw[j] >> 5) & 3u;
+                        const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                        const uint32_t key = (kind << 16) | full;
+                        bool dropped = false;
+                        for (int q = 0; q < dropped_known; q++) dropped |= W.coll[q] == key;
+                        if (dropped && (fl[j] & 1u)) { bits_lane -= (fl[j] >> 4) & 7u; nb[j] -= (fl[j] >> 4) & 7u; }
+                    }
+                }
+                const uint32_t bin_ = wave_incl_scan_u32(bits_lane);
+                uint32_t off = pos + bin_ - bits_lane;
+                uint32_t offs[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { offs[j] = off; off += nb[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) put_bits_always(fr, P.frw, sink, offs[j], (int)(pw[j] & 31u), vq[j]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) W.gtab[(fl[j] & 1u) ? slot[j] : 512u + 2u * (uint32_t)lane] = offs[j] | vw[j];
+                WAVE_SYNC();
+#pragma unroll
+                for (int j = 0; j < 4; j++) atomicAdd(&W.gtab[(fl[j] & 4u) ? slot[j] : 512u + 2u * (uint32_t)lane], vw[j]);
+                WAVE_SYNC();
+                uint32_t hit = 0;
+                uint32_t xs[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    xs[j] = W.gtab[(fl[j] & 2u) ? slot[j] : 512u + 2u * (uint32_t)lane];
+                    const uint32_t coll = ((fl[j] >> 1) & 1u) * ((xs[j] >> 16) == marker ? 1u : 0u);
+                    hit |= coll;
+                    put_bits_always(fr, P.frw, sink, xs[j] & 0xffffu, (int)(((fl[j] >> 4) & 7u) * ((fl[j] >> 1) & 1u) * (1u - coll)), xs[j] >> 16);
+                }
+                if (attempt == 0 && __ballot(hit != 0)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
+                            const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
+                            const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                            const int q = atomicAdd(&W.ncoll, 1);
+                            if (q < 32) W.coll[q] = ((uint32_t)kind << 16) | full;
+                        }
+                }
+                WAVE_SYNC();
+                {
+                    const uint32_t gtot = wave_last(gin);
+                    const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
+                    b3 += t3; b5 += t5; b11 += t11;
+                    baseg = (uint32_t)((b3 / 3) & 255) | ((uint32_t)((b5 / 3) & 255) << 8) | ((uint32_t)((b11 >> 1) & 255) << 16);
+                    basem = (uint32_t)(b3 % 3) | ((uint32_t)(b5 % 3) << 2) | ((uint32_t)(b11 & 1) << 4);
+                }
+                pos += wave_last(bin_);
+            }
+            // a trailing group that never got its last member is written as it stands
+            WAVE_SYNC();
+            if (lane == 0) {
+                auto tail = [&](int kind, int grp, uint32_t x, int gbits) {
+                    if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
+                    else if (attempt == 0) { const int q = W.ncoll++; if (q < 32) W.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
+                };
+                if (b3 % 3) tail(0, b3 / 3, W.gtab[(b3 / 3) & 127], 5);
+                if (b5 % 3) tail(1, b5 / 3, W.gtab[128 + ((b5 / 3) & 127)], 7);
+                if (b11 & 1) tail(2, b11 >> 1, W.gtab[256 + ((b11 >> 1) & 255)], 7);
+                if (attempt == 0 && W.ncoll) L.any_coll = 1;
+            }
+        }
+        __syncthreads();
+        if (attempt == 1 || !L.any_coll) break;
+        // a dropped field moves everything behind it: the frame is erased and every block packed again with its recorded
+        // fields at width 0
+        __syncthreads();
+        for (int i = tid; i < P.frw / 4; i += 384) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
+        {
+            const int nc = __builtin_amdgcn_readfirstlane(W.ncoll);
+            dropped_known = nc < 32 ? nc : 32;
+        }
+        __syncthreads();
+    }
+
+    // ---- frame end (:1599-1638): the two CRC regions on two wavefronts, then the frame goes out ----
+    const int fs58 = (fs >> 1) + (fs >> 3);
+    if (b == 0) {
+        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
+        crc1 = gf_mul(P.crc_inv, crc1);
+        if (lane == 0) L.crc[0] = crc1;
+    } else if (b == 1) {
+        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
+        if (lane == 0) L.crc[1] = crc2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        fr[0] = (fr[0] & 0xffff0000u) | (L.crc[0] & 0xffff);                      // bytes 2,3
+        const int p = 2 * fs - 2;                                                     // even -> inside one dword
+        const int shft = 16 - 8 * (p & 3);
+        fr[p >> 2] = (fr[p >> 2] & ~(0xffffu << shft)) | ((L.crc[1] & 0xffff) << shft);
+    }
+    __syncthreads();
+    uint8_t *dst = P.frames + fidx * P.frame_stride;
+    for (int i = tid; i < (2 * fs + 3) / 4; i += 384) {
+        const uint32_t v = __builtin_bswap32(fr[i]);
+        const int rem = 2 * fs - 4 * i;
+        if (rem >= 4) *reinterpret_cast<uint32_t *>(dst + 4 * i) = v;
+        else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
 #ifdef PACK_STAMPS
 extern "C" __attribute__((visibility("default"))) int ac3mi_debug_pack_cycles(unsigned long long *out8, int reset)
 {
@@ -1579,12 +1962,22 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.marker = getenv("AC3MI_ENC_MARKER") ? atoi(getenv("AC3MI_ENC_MARKER")) : 128;      // test aid (read per launch), see PackParams::marker
     static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
     const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
-    if (E.frames_per_stream > 1 && E.n_streams < 5120 && E.ws_snr) {
-        // few long streams: searches per stream, then all frames packed at once
-        P.memo = E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
-        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), 16, stream, P);
+    // The SNR-offset searches run one wavefront per stream (PART 1; for few long streams behind PART 3's frame-parallel
+    // tabulation), then every frame is packed by a workgroup of six wavefronts, one per audio block (enc_packb_kernel).
+    // Measured per call on one-frame streams, cold (profiles/encode_cold.py): 64 frames 0.147 against 0.219 ms with the
+    // one-kernel packer, 1 024: 0.222 / 0.261, 4 096: 0.599 / 0.546, 65 536: 7.9 / 7.0 - a frame's chain is a sixth as long,
+    // but a workgroup's wavefronts wait for each other five times per frame, so the chip holds fewer busy wavefronts: the
+    // block packer takes batches of up to 2 048 frames (the byte-stream layer's chunks), the one-kernel packer the rest.
+    // E.pack_mode (ac3mi_set_encode_mode): 0 = that rule, 1 = never, 2 = always the block packer.
+    const unsigned nfr = (unsigned)E.n_streams * (unsigned)E.frames_per_stream;
+    const bool long_streams = E.frames_per_stream > 1 && E.n_streams < 5120;
+    const bool packb = E.pack_mode == 2 || (E.pack_mode == 0 && nfr <= 2048);
+    if (E.ws_snr && (packb || long_streams)) {
+        P.memo = long_streams && E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
+        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3(nfr), dim3(64), 16, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 16, stream, P);
-        hipLaunchKernelGGL(enc_pack_kernel<2>, dim3((unsigned)E.n_streams * (unsigned)E.frames_per_stream), dim3(64), fr_lds, stream, P);
+        if (packb) hipLaunchKernelGGL(enc_packb_kernel, dim3(nfr), dim3(384), fr_lds, stream, P);
+        else hipLaunchKernelGGL(enc_pack_kernel<2>, dim3(nfr), dim3(64), fr_lds, stream, P);
     } else {
         hipLaunchKernelGGL(enc_pack_kernel<0>, dim3(E.n_streams), dim3(64), fr_lds, stream, P);
     }

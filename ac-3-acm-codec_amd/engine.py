@@ -244,6 +244,11 @@ class Engine:
         (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
+    def set_encode_mode(self, mode):
+        """0 = choose by batch size, 1 = one wavefront per stream / frame packs, 2 = one wavefront per audio block packs
+        (ac3mi_set_encode_mode)."""
+        self._check(self.lib.ac3mi_set_encode_mode(ctypes.c_void_p(self.ctx), int(mode)))
+
     def set_mix_state(self, pending=None, flags=None):
         """liba52's overlap bookkeeping around frames with surround level 0 (ac3mi_set_mix_state): `pending` float32 shaped
         like the delay array, `flags` int32 [S][6], both zero for new streams and updated in place by the decode calls that

@@ -153,6 +153,15 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
 #define AC3MI_STATUS_REUSE0 0x200u
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 
+/* How ac3mi_encode_batch / ac3mi_transcode_batch pack a frame once its SNR offsets are found (new; same bytes either way):
+ *   1  one wavefront per stream searches and packs its frames in order (few long streams: searches per stream, then one
+ *      wavefront per frame packs);
+ *   2  searches per stream, then a workgroup of six wavefronts per frame, one per audio block: every block's first bit
+ *      follows from bit counts, so the six pack at once into the frame they share in LDS (a third less latency per frame;
+ *      ahead for batches of up to about 2 000 frames);
+ *   0  (default) 2 for up to 2 048 frames per call, else 1. */
+int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode);
+
 /* Workspace bound (new; results do not depend on it, except for frames flagged AC3MI_STATUS_REUSE0 at a tile boundary).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
  * their intermediates (coefficient planes, MDCT coefficients, exponents, PCM between decoder and encoder: 37 / 60 /
  * 152 KB per frame) in workspaces owned by the context.  A batch of more than `frames` frames goes through in tiles

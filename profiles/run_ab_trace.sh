@@ -1,13 +1,14 @@
 #!/bin/bash
-# gpurun -- 'bash profiles/run_ab_trace.sh TAG S MODES...': kernel trace of profiles/decode_ab.py (kernels back to back)
+# gpurun -- 'bash profiles/run_ab_trace.sh TAG S MODES...': kernel trace of profiles/decode_ab.py (kernels back to back);
+# SCRIPT=profiles/encode_cold.py in the environment traces that script instead
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export AC3MI_NO_OVERLAP=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/profiles/decode_ab.py "$@" > $OUT/trace.log 2>&1
-grep "mode" $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/${SCRIPT:-profiles/decode_ab.py} "$@" > $OUT/trace.log 2>&1
+grep -E "mode|cold" $OUT/trace.log
 python3 - <<PY
 import csv
 rows = list(csv.DictReader(open("$OUT/trace/t_kernel_stats.csv")))

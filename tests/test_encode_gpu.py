@@ -297,3 +297,32 @@ def test_batch_shape_paths_agree(engine):
     assert torch.equal(last.cpu(), last1.cpu()) and torch.equal(csnr.cpu(), csnr1.cpu())
     want, _ = _oracle(pcm, 6, 384000)
     assert np.array_equal(whole.cpu().numpy()[:, :, :1536], want)
+
+
+@pytest.mark.parametrize("nch,bitrate,freq", [(6, 384000, 48000), (2, 192000, 44100), (1, 96000, 32000), (3, 48000, 24000)])
+def test_block_packer_equals_the_stream_packer(engine, nch, bitrate, freq):
+    """ac3mi_set_encode_mode: 1 = one wavefront per stream searches and packs (per frame for few long streams), 2 = searches
+    per stream, then six wavefronts per frame - one per audio block - pack at once from bit counts.  Same frames, same
+    carry-over state, same bap taps, on one-frame and on multi-frame streams (the last configuration starves: frames whose
+    search fails, ENC/ac3enc.cpp:930-933)."""
+    import os
+    import torch
+    pkg = H.pkg()
+    desc = pkg.EncodeDesc(freq, bitrate, nch)
+    chmap = H.CHMAP6[:nch] if nch == 6 else tuple(range(nch))
+    for S, F in ((9, 1), (3, 5)):
+        pcm = torch.from_numpy(np.stack([H.gen_pcm(F, nch, seed=400 + 7 * s + nch, kind=("bursts", "music", "quiet", "noise", "strobe")[s % 5])
+                                         for s in range(S)]).reshape(S, F, 1536, nch)).cuda()
+        res = {}
+        try:
+            for mode in (1, 2):
+                engine.set_encode_mode(mode)
+                last = torch.zeros((S, nch, 256), dtype=torch.int16, device="cuda")
+                csnr = torch.full((S,), 40, dtype=torch.int32, device="cuda")
+                frames, taps = engine.encode_batch(desc, pcm, chmap, last, csnr, taps=True)
+                engine.sync()
+                res[mode] = [x.cpu().numpy() for x in (frames, last, csnr, taps["bap"], taps["snr"])]
+        finally:
+            engine.set_encode_mode(int(os.environ.get("AC3MI_ENCODE_MODE", "0")))
+        for a, b in zip(res[1], res[2]):
+            assert np.array_equal(a, b), (S, F)

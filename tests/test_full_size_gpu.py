@@ -78,8 +78,8 @@ def test_encode_full_size(engine):
 def test_transcode_full_size(engine):
     """configs[4]'s per-GPU step at bench size: 65 536 frames decoded to s16 and re-encoded in one ac3mi_transcode_batch
     call from fresh stream state.  Every frame: decoder status clean, both CRCs of the new frame; the first 256 streams
-    against the oracle's decode (<= 1 s16 step, the float PCM may differ by an ulp at bias 384) - and where the oracle's
-    samples equal the engine's, its re-encoding byte for byte."""
+    against the oracle's decode (<= 1 s16 step, the float PCM may differ by an ulp at bias 384) and, from the engine's
+    own samples, against the oracle's encoding byte for byte."""
     import torch
     import bench
     pkg = H.pkg()
@@ -118,7 +118,6 @@ def test_transcode_full_size(engine):
     src = frames[:n].cpu().numpy().reshape(n, -1)[:, :fb]
     got16 = s16[:n].cpu().numpy().reshape(n, 6, 256, 6)
     ref16 = np.zeros((256, 6), np.int16)
-    same = []
     for i in range(n):
         pcmf, errs, oflags = H.orc_decode(src[i:i + 1], 7 | 16 | 32, 1.0, 384.0)
         assert errs == 0
@@ -127,11 +126,9 @@ def test_transcode_full_size(engine):
             O.orc_convert_s16(H.P(np.ascontiguousarray(pcmf[0, b]), H.fp), H.P(ref16, H.i16p), oflags)
             frame16[b] = ref16
         assert np.abs(got16[i].astype(np.int32) - frame16.astype(np.int32)).max() <= 1, i
-        if np.array_equal(got16[i], frame16):
-            same.append(i)
-    assert len(same) > n // 2
-    want = _oracle_frames(got16[same].reshape(len(same), 1536, 6), len(same))
-    assert np.array_equal(host[same], want)
+    # ... and the encoder half on exactly the samples the decoder half produced
+    want = _oracle_frames(got16.reshape(n, 1536, 6), n)
+    assert np.array_equal(host[:n], want), np.nonzero((host[:n] != want).any(axis=1))[0][:8]
 
 
 def test_mixed_blocks_downmix_full_size(engine):
