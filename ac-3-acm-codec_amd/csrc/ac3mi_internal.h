@@ -121,9 +121,6 @@ struct DecodeLaunch {
     uint8_t *ws_rows = nullptr;     // [S][F][6][7][512]
     float *ws_cplco = nullptr;      // [S][F][6][90]
     uint32_t *ws_fpos = nullptr;    // [S][F]
-    // optional: the mantissa kernel goes to this stream (it waits there for ev_parsed, recorded after the parse kernel)
-    hipStream_t mant_stream = nullptr;
-    hipEvent_t ev_parsed = nullptr;
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 // decode_wg.hip: one workgroup per stream; X == nullptr: coefficient planes (+ taps) to HBM as launch_decode does;
@@ -169,13 +166,8 @@ struct ac3mi_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
-    // second stream for the transform of a large decode batch: it overlaps the next chunk's front end
+    // second stream: the byte-stream layer's PCIe copies beside the kernels (stream.hip)
     hipStream_t stream2;
-    hipEvent_t ev_chunk[4], ev_mid[4], ev_join;
-    // third stage of the split decode front end: mantissa kernels
-    hipStream_t stream3;
-    hipEvent_t ev_parse[4];
-    int split_chunks;
     int encode_mode;        // ac3mi_set_encode_mode
     ac3mi::DeviceTables tab;
     // decode workspace (coefficient planes + block-switch flags between the two kernels)
@@ -193,7 +185,6 @@ struct ac3mi_ctx {
     // optional liba52-exact overlap state around frames with surround level 0 (ac3mi_set_mix_state)
     float *mix_pending;
     int32_t *mix_flags;
-    bool no_overlap;        // AC3MI_NO_OVERLAP in the environment: no chunk pipelines (clean per-kernel profiles)
     long long tile_frames;  // workspace bound: batches above this many frames go through in tiles of whole streams (0 = never)
     int decode_mode;        // ac3mi_set_decode_mode
     uint32_t *ws_draws;     // [S][F] draw counts + [S][F] u16 frame-start LFSR states (decode, frame-parallel)

@@ -399,11 +399,6 @@ static int ctx_init(ac3mi_ctx *ctx)
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_parse[i], hipEventDisableTiming));
-    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
-    for (int i = 0; i < 4; i++) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_mid[i], hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     std::vector<float> win(256);
     std::vector<float2> twl(128), tws(128);
     build_host_tables(win.data(), twl.data(), tws.data());
@@ -467,12 +462,6 @@ ac3mi_ctx *ac3mi_create(int device)
         const int m = atoi(e);
         if (m >= 0 && m <= 2) ctx->encode_mode = m;
     }
-    ctx->split_chunks = 2;
-    if (const char *e = getenv("AC3MI_SPLIT_CHUNKS")) {         // profiling aid: chunks of the three-stage decode pipeline
-        const int m = atoi(e);
-        if (m >= 1 && m <= 4) ctx->split_chunks = m;
-    }
-    ctx->no_overlap = getenv("AC3MI_NO_OVERLAP") != nullptr;     // profiling aid: one chunk, one stream, kernels back to back
     ctx->ws_draws = nullptr;
     ctx->ws_draws_bytes = 0;
     ctx->ws_split = nullptr;
@@ -510,11 +499,6 @@ void ac3mi_destroy(ac3mi_ctx *ctx)
     (void)hipFree(ctx->tab.enc);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_chunk[i]);
-    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_mid[i]);
-    (void)hipEventDestroy(ctx->ev_join);
-    for (int i = 0; i < 4; i++) (void)hipEventDestroy(ctx->ev_parse[i]);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1004,10 +988,11 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     }
     // A large batch goes through in two chunks of streams: the (HBM-bound) transform of chunk i runs on a
     // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
-    // (one-kernel front end, measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 5.06 / 4.93 / 4.94 / 5.04 ms.)  The split front end
-    // adds a stage: parse kernel (scalar-unit-bound) of chunk k+1 on stream 1, mantissa kernel (vector-bound) of chunk k on
-    // stream 3, transform (HBM-bound) of chunk k-1 on stream 2.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap ? (split ? ctx->split_chunks : 2) : 1;
+    // One pass over the batch, kernels back to back on the context's stream.  Rounds 1-2 sent large batches through in two
+    // chunks with the transform of chunk k on a second stream beside the front end of chunk k+1 (and round 3 tried the
+    // mantissa kernel on a third): measured again with the split front end, 1 / 2 / 3 / 4 chunks = 3.545 / 3.549 / 3.572 /
+    // 3.616 ms per 65 536 frames - a kernel of this size fills the chip, only the tails overlap - so the pipeline is gone.
+    const int n_chunks = 1;
     const size_t F = (size_t)frames_per_stream;
     for (int k = 0; k < n_chunks; k++) {
         const int s0 = (int)((long long)n_streams * k / n_chunks), s1 = (int)((long long)n_streams * (k + 1) / n_chunks);
@@ -1043,16 +1028,8 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
         }
-        hipStream_t fs = ctx->stream;                       // where the front end of the chunk ends
-        if (split && n_chunks > 1) { D.mant_stream = ctx->stream3; D.ev_parsed = ctx->ev_parse[k]; fs = ctx->stream3; }
         HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
-
         hipStream_t xs = ctx->stream;
-        if (n_chunks > 1) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_chunk[k], fs));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_chunk[k], 0));
-            xs = ctx->stream2;
-        }
         X.coef = D.coef;
         X.blksw = D.blksw;
         X.zs = D.zs;
@@ -1070,10 +1047,6 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         X.frames = frames_per_stream;
         X.bias = desc->bias;
         HIPCHK(ctx, launch_xform(ctx->tab, X, xs));
-    }
-    if (n_chunks > 1) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     return AC3MI_OK;
 }
@@ -1333,9 +1306,10 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
     const bool split = !fused && use_split(ctx);
     if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
-    // Two chunks of streams.  Stream 1 (instruction-bound kernels): front end of chunk k+1, then the encoder of
-    // chunk k; stream 2 (HBM-bound kernels): transform and s16 conversion of chunk k in their shadow.
-    const int n_chunks = nfr >= 16384 && n_streams >= 4 && !ctx->no_overlap && !fused ? (split ? ctx->split_chunks : 2) : 1;       // (one-kernel front end) measured on 65536 frames, 1 / 2 / 3 / 4 chunks: 12.4-12.5 / 12.1 / 12.2-12.3 / 12.6 ms
+    // Decoder front end, transform to s16, encoder: back to back on the context's stream.  (Until round 2 two chunks were
+    // pipelined over two streams; profiles/transcode_overlap.py measured 12.20 ms with and 12.23 - 12.27 ms without it per
+    // 65 536 cold frames, and the sum of the separate decode-to-s16 and encode calls at 12.1 - 12.2 ms: no overlap to keep.)
+    const int n_chunks = 1;
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {
         const int s0 = chunk_lo(k), ns = chunk_lo(k + 1) - s0;
@@ -1366,7 +1340,6 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
             const SplitWs w = split_ws(ctx, nfr, f0);
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
-            if (n_chunks > 1) { D.mant_stream = ctx->stream3; D.ev_parsed = ctx->ev_parse[k]; }
         }
         if (fused) {
             XformLaunch Y = X;
@@ -1432,26 +1405,9 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         G.tap_snr = nullptr;
         return launch_encode(ctx->tab, G, ctx->stream);
     };
-    if (n_chunks == 1) {
-        HIPCHK(ctx, front(0));
-        if (!fused) HIPCHK(ctx, middle(0, ctx->stream));
-        HIPCHK(ctx, back(0));
-        return AC3MI_OK;
-    }
-    hipEvent_t *ev = ctx->ev_chunk;                     // front end of chunk k done
-    for (int k = 0; k < n_chunks; k++) {
-        HIPCHK(ctx, front(k));
-        HIPCHK(ctx, hipEventRecord(ev[k], split ? ctx->stream3 : ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ev[k], 0));
-        HIPCHK(ctx, middle(k, ctx->stream2));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_mid[k], ctx->stream2));
-        if (k > 0) {
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_mid[k - 1], 0));
-            HIPCHK(ctx, back(k - 1));
-        }
-    }
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_mid[n_chunks - 1], 0));
-    HIPCHK(ctx, back(n_chunks - 1));
+    HIPCHK(ctx, front(0));
+    if (!fused) HIPCHK(ctx, middle(0, ctx->stream));
+    HIPCHK(ctx, back(0));
     return AC3MI_OK;
 }
 

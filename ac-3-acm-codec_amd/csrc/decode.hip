@@ -814,15 +814,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
         M.lfeon = L.lfeon;
         M.n_in = P.n_in;
         M.nfchans = P.nfchans;
-        hipStream_t ms = stream;
-        if (L.mant_stream && L.mant_stream != stream) {
-            hipError_t e = hipEventRecord(L.ev_parsed, stream);
-            if (e != hipSuccess) return e;
-            e = hipStreamWaitEvent(L.mant_stream, L.ev_parsed, 0);
-            if (e != hipSuccess) return e;
-            ms = L.mant_stream;
-        }
-        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, ms, M);
+        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, stream, M);
         return hipGetLastError();
     }
     if (!L.frame_parallel) {

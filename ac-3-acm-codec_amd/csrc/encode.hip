@@ -543,8 +543,6 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
     __shared__ int16_t in[512];
     __shared__ c16 z[128];
     __shared__ int32_t out[256];
-    __shared__ int16_t xc[128], xs[128], ct[64], sn[64];
-    __shared__ uint8_t rev[128];
     __shared__ ExpLDS XL;
 
     const int lane = threadIdx.x;
@@ -566,15 +564,23 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
     int wa[4], wb[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { wa[k] = P.tab->win[lane + 64 * k]; wb[k] = P.tab->win[255 - lane - 64 * k]; }
-    for (int i = lane; i < 128; i += 64) { xc[i] = P.tab->xcos[i]; xs[i] = P.tab->xsin[i]; rev[i] = P.tab->bitrev[i]; }
-    ct[lane] = P.tab->cos[lane];
-    sn[lane] = P.tab->sin[lane];
     for (int i = lane; i < 256; i += 64) {
         XL.t.latab[i] = P.tab->latab[i];
         XL.t.band_of_bin[i] = P.tab->band_of_bin[i];
     }
     if (lane < 50) XL.t.hth[lane] = P.tab->hth[lane][P.x.fscod];
     if (lane < 52) XL.t.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0;
+    // rotation factors and bit-reversed places of the lane's two points i = lane, lane + 64 (:578-591, :496-504), and the
+    // twiddles of its butterfly in passes 2..6 (:533-567: twiddle index (lane mod nloops) * nblocks): constant per lane
+    int xcv[2], xsv[2], revv[2], twc[5], tws[5];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { xcv[k] = P.tab->xcos[lane + 64 * k]; xsv[k] = P.tab->xsin[lane + 64 * k]; revv[k] = P.tab->bitrev[lane + 64 * k]; }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int nloops = 4 << k, nblocks = 16 >> k, m = lane & (nloops - 1);
+        twc[k] = P.tab->cos[m * nblocks];
+        tws[k] = -P.tab->sin[m * nblocks];
+    }
 
     const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
     // samples lane, 64+lane, 128+lane, 192+lane of: the block before (history), this block, and - in flight while
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
         newv[k] = frame_pcm[(size_t)j * P.nch];
     }
     for (int blk = 0; blk < 6; blk++) {
-        // ---- 512 input samples: 256 old + 256 new (:1673-1683) ----
+        // ---- 512 input samples: 256 old + 256 new (:1673-1683), windowed (:1686-1693) - in registers ----
+        int win_[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = lane + 64 * k;
@@ -597,27 +604,20 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
                 if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
                 else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
             }
-            // window (:1686-1693)
-            in[j] = (int16_t)((oldv[k] * wa[k]) >> 15);
-            in[256 + j] = (int16_t)((newv[k] * wb[k]) >> 15);
+            win_[k] = (int16_t)((oldv[k] * wa[k]) >> 15);
+            win_[4 + k] = (int16_t)((newv[k] * wb[k]) >> 15);
             oldv[k] = newv[k];
         }
-        WAVE_SYNC();
         // ---- block floating point (:1697-1700) ----
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int v = in[lane + 64 * k];
-            acc |= v < 0 ? -v : v;
-        }
+        for (int k = 0; k < 8; k++) acc |= win_[k] < 0 ? -win_[k] : win_[k];
         acc = wave_or(acc);
         int v = 14 - ilog2u((unsigned)acc);
         if (v < 0) v = 0;
         const int shift = v - 9;
-        if (v > 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(in[lane + 64 * k] * (1 << v));
-        }
+        for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(win_[k] * (1 << v));
         WAVE_SYNC();
         // ---- rotation + pre-rotation (:578-591), stored bit-reversed (:496-504) ----
 #pragma unroll
@@ -626,55 +626,57 @@ __global__ __launch_bounds__(64, 6) void enc_mdct_kernel(const MdctParams P)
             auto rot = [&](int t) -> int { return t < 128 ? (int)(int16_t)(-in[t + 384]) : (int)in[t - 128]; };
             const int re = (rot(2 * i) - rot(511 - 2 * i)) >> 1;
             const int im = (-(rot(256 + 2 * i) - rot(255 - 2 * i))) >> 1;
-            const int c = -xc[i], sx = xs[i];
+            const int c = -xcv[k], sx = xsv[k];
             c16 t;
             t.re = (int16_t)((re * c - im * sx) >> 15);
             t.im = (int16_t)((re * sx + c * im) >> 15);
-            z[rev[i]] = t;
+            z[revv[k]] = t;
         }
         WAVE_SYNC();
-        // ---- pass 0 (:508-515) ----
+        // ---- the seven passes (:508-567) in registers: the lane's butterfly of pass k takes the points ip = (lane / d) 2d +
+        //      lane mod d and ip + d (d = 2^k); between two passes every lane trades ONE point with lane ^ d (the upper half of
+        //      a 2d-lane group gives its first point and keeps the second, the lower half the other way round).  Same operands,
+        //      shifts and 16-bit truncations as the reference's in-place loops, no LDS round trip per pass. ----
+        int pr, pi, qr, qi;
         {
-            c16 p = z[2 * lane], q = z[2 * lane + 1];
-            bfly(p, q, p.re, p.im, q.re, q.im);
-            z[2 * lane] = p;
-            z[2 * lane + 1] = q;
+            const c16 p0 = z[2 * lane], q0 = z[2 * lane + 1];
+            pr = p0.re; pi = p0.im; qr = q0.re; qi = q0.im;
         }
-        WAVE_SYNC();
-        // ---- pass 1 (:519-529): twiddles 1 and -j ----
-        {
-            const int base = 4 * (lane >> 1) + (lane & 1);
-            c16 p = z[base], q = z[base + 2];
-            if (lane & 1) bfly(p, q, p.re, p.im, q.im, -q.re);
-            else bfly(p, q, p.re, p.im, q.re, q.im);
-            z[base] = p;
-            z[base + 2] = q;
-        }
-        WAVE_SYNC();
-        // ---- passes 2..6 (:533-567) ----
-        for (int nloops = 4, nblocks = 16; nblocks; nloops <<= 1, nblocks >>= 1) {
-            const int j = lane / nloops, m = lane - j * nloops;
-            const int ip = j * 2 * nloops + m, iq = ip + nloops;
-            c16 p = z[ip], q = z[iq];
-            if (m == 0) bfly(p, q, p.re, p.im, q.re, q.im);
-            else {
-                const int l = m * nblocks;
-                const int c = ct[l], sx = -sn[l];
-                const int tr = (c * q.re - sx * q.im) >> 15;
-                const int ti = (c * q.im + q.re * sx) >> 15;
-                bfly(p, q, p.re, p.im, tr, ti);
-            }
-            z[ip] = p;
-            z[iq] = q;
-            WAVE_SYNC();
-        }
-        // ---- post-rotation (:596-602) ----
+        auto bfly_r = [&](int ax, int ay) {
+            const int bx = pr, by = pi;
+            pr = (int16_t)((bx + ax) >> 1);
+            pi = (int16_t)((by + ay) >> 1);
+            qr = (int16_t)((bx - ax) >> 1);
+            qi = (int16_t)((by - ay) >> 1);
+        };
+        auto trade = [&](int d) {
+            const bool up = (lane & d) != 0;
+            const int sr = up ? pr : qr, si = up ? pi : qi;
+            const int rr = __shfl_xor(sr, d, 64), ri = __shfl_xor(si, d, 64);
+            pr = up ? rr : pr; pi = up ? ri : pi;
+            qr = up ? qr : rr; qi = up ? qi : ri;
+        };
+        bfly_r(qr, qi);                                                     // pass 0
+        trade(1);
+        if (lane & 1) bfly_r(qi, -qr); else bfly_r(qr, qi);                 // pass 1: twiddles 1 and -j
+        trade(2);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = lane + 64 * k;
-            const int re = z[i].re, im = z[i].im, sx = xs[i], c = xc[i];
-            out[2 * i] = (re * c + sx * im) >> 15;
-            out[255 - 2 * i] = (re * sx - im * c) >> 15;
+        for (int k = 0; k < 5; k++) {                                       // passes 2..6
+            const int nloops = 4 << k;
+            const int c = twc[k], sx = tws[k];
+            const int tr = (c * qr - sx * qi) >> 15;
+            const int ti = (c * qi + qr * sx) >> 15;
+            const bool plain = (lane & (nloops - 1)) == 0;
+            bfly_r(plain ? qr : tr, plain ? qi : ti);
+            if (k < 4) trade(nloops);
+        }
+        // ---- post-rotation (:596-602): the lane now holds points lane and lane + 64 ----
+        {
+            const int sx0 = xsv[0], c0 = xcv[0], sx1 = xsv[1], c1 = xcv[1];
+            out[2 * lane] = (pr * c0 + sx0 * pi) >> 15;
+            out[255 - 2 * lane] = (pr * sx0 - pi * c0) >> 15;
+            out[2 * (lane + 64)] = (qr * c1 + sx1 * qi) >> 15;
+            out[255 - 2 * (lane + 64)] = (qr * sx1 - qi * c1) >> 15;
         }
         WAVE_SYNC();
         // ---- exponents (:1707-1722) ----

@@ -321,7 +321,7 @@ def test_block_packer_equals_the_stream_packer(engine, nch, bitrate, freq):
                 csnr = torch.full((S,), 40, dtype=torch.int32, device="cuda")
                 frames, taps = engine.encode_batch(desc, pcm, chmap, last, csnr, taps=True)
                 engine.sync()
-                res[mode] = [x.cpu().numpy() for x in (frames, last, csnr, taps["bap"], taps["snr"])]
+                res[mode] = [x.cpu().numpy() for x in (frames, last, csnr, taps["bap"], taps["snroffst"], taps["exp_strategy"])]
         finally:
             engine.set_encode_mode(int(os.environ.get("AC3MI_ENCODE_MODE", "0")))
         for a, b in zip(res[1], res[2]):
