@@ -745,16 +745,16 @@ static int ensure_split(ac3mi_ctx *ctx, size_t nfr)
     return AC3MI_OK;
 }
 
-// one workgroup per stream (decode_wg.hip)?  Its eight wavefronts cut the latency of a frame to a third (64 - 256 one-frame
-// streams: 0.09 ms against 0.24 ms) and nothing but the frame and the PCM touches HBM, but a workgroup's wavefronts wait for
-// each other at the block's barriers, so the chip holds fewer busy wavefronts than with one wavefront per stream: measured
-// on one-frame streams it is ahead up to about 1 500 streams (256: 0.086 against 0.23 ms; 1 024: 0.19 against 0.26 ms;
-// 2 048: 0.36 against 0.26 ms; 65 536: 10.7 against 4.4 ms).  auto: batches of up to 1 024 streams of at most four frames;
-// mode 3 forces it.
+// one workgroup per stream (decode_wg.hip)?  Its eight wavefronts cut the latency of a frame to a third and nothing but the
+// frame and the PCM touches HBM, but a workgroup's wavefronts wait for each other at the block's barriers, so the chip holds
+// fewer busy wavefronts than the other front ends.  Measured on one-frame streams to s16 (round 3, profiles/decode_ab.py;
+// fused / split front end + transform / one-kernel front end + transform): 64 streams 0.084 / 0.118 / 0.167 ms, 256: 0.086 /
+// 0.121 / 0.165, 1 024: 0.188 / 0.150 / 0.184, 2 048: 0.362 / 0.186 / 0.206, 4 096: 0.70 / 0.28 / 0.28, 65 536: 10.7 / 3.5 / 4.2.
+// auto: batches of up to 512 streams of at most four frames (round 2: 1 024, against the one-kernel front end); mode 3 forces it.
 static bool use_wg_kernel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
     if (ctx->decode_mode) return ctx->decode_mode == 3;
-    return n_streams <= 1024 && frames_per_stream <= 4;
+    return n_streams <= 512 && frames_per_stream <= 4;
 }
 
 static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)

@@ -138,13 +138,13 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
  *      state each frame starts from, then one wavefront per frame decodes them all at once;
  *   3  one 512-thread workgroup per stream: a wavefront per channel beside a parser and a transformer wavefront, the
  *      coefficient planes stay in LDS and the transform is fused in (a third of the latency of variant 1 per frame,
- *      no plane traffic in HBM; ahead for batches of up to about 1 500 streams);
+ *      no plane traffic in HBM; ahead for batches of up to about 700 streams);
  *   4  the split front end, parse kernel per stream: one wavefront per stream parses side information, decodes
  *      exponents and allocates bits, frames in order, and only COUNTS each block's mantissas (from per-row totals); it
  *      leaves a descriptor per audio block plus the exponent / allocation rows that changed, and a second kernel unpacks
  *      and dequantises every block with a wavefront of its own (six per frame), before the transform kernel;
  *   5  the same with the parse kernel per frame and variant 2's prefix pass over the dither draws (few, long streams);
- *   0  (default) choose by batch shape: 3 for up to 1 024 streams of at most four frames, else 4 or 5.
+ *   0  (default) choose by batch shape: 3 for up to 512 streams of at most four frames, else 4 or 5.
  * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
  * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and
  * the fused and the separate transform execute the same arithmetic.  A frame whose block 0 reuses state it did not send
