@@ -96,6 +96,9 @@ struct alignas(16) PackLDS {
     // kind << 16 | group, first attempt of a block's packing
     uint32_t coll[32];
     int ncoll;
+    // the frame's run-start rows in (block, channel) order, for the search's sweeps: byte offset of the row's encoded
+    // exponents (bits 0-13) | LFE row (7 coefficients, bit 14) | blocks the run covers (bits 16-21) | mask row (24-29)
+    uint32_t rowdesc[36];
 };
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
@@ -969,6 +972,16 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 row_set = __ballot(lane < 36 && c6 < nch && L.strat[lane < 36 ? b6 : 0][c6] != 0);
                 const int c8 = lane >> 3, b8 = lane & 7;
                 run_starts = __ballot(b8 < 6 && c8 < nch && L.strat[b8 < 6 ? b8 : 0][c8 < 6 ? c8 : 0] != 0);
+                // one descriptor per run-start row, computed by the row's lane, compacted in row order: the sweeps then
+                // walk a list instead of deriving block range, channel and addresses from bit sets (scalar work per row
+                // and sweep: the scalar unit is what bounds the search)
+                if (lane < 36 && ((row_set >> lane) & 1)) {
+                    const uint32_t later = (uint32_t)((run_starts >> (8 * c6)) & 0x3f) | 0x40u;       // bit b: block b of this channel sends exponents
+                    const int b1 = __builtin_ctz(later >> (b6 + 1)) + b6 + 1;
+                    const uint32_t cover = ((1u << b1) - 1u) & ~((1u << b6) - 1u);
+                    const uint32_t d = (uint32_t)((b6 * nch + c6) * 256) | ((P.lfe && c6 == nch - 1) ? 1u << 14 : 0u) | (cover << 16) | ((uint32_t)lane << 24);
+                    L.rowdesc[__builtin_popcountll(row_set & ((1ull << lane) - 1ull))] = d;
+                }
             }
             // ---- fixed side information (:880-916) ----
             {
@@ -1034,28 +1047,21 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
 #pragma unroll
                 for (int c = 0; c < ENC_NC; c++) acc[B][c] = 0;
             {
-                // one run-start row per step: four bins per lane from one dword (HBM/L2), the next row's dword in flight
-                // (the exponent dwords of the next three rows are in flight while one is costed)
-                uint64_t todo = row_set;
-                auto row_of = [&](uint64_t t, int fallback) { return t ? (int)__builtin_ctzll(t) : fallback; };
-                auto fetch = [&](int row) { return *reinterpret_cast<const uint32_t *>(ex + ((size_t)(row / 6) * nch + (row % 6)) * 256 + 4 * lane); };
-                int r = row_of(todo, 0);
-                uint64_t t1 = todo & (todo - 1), t2 = t1 & (t1 - 1);
-                int r1 = row_of(t1, r), r2 = row_of(t2, r1);
-                uint32_t ev = fetch(r), ev1 = fetch(r1), ev2 = fetch(r2);
+                // one run-start row per step: four bins per lane from one dword (HBM/L2); the exponent dwords of the next
+                // three rows are in flight while one is costed
+                const int nrows = __builtin_popcountll(row_set);
+                auto desc_of = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rowdesc[i < nrows ? i : nrows - 1]); };
+                auto fetch = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(ex + (d & 0x3fffu) + 4 * lane); };
+                uint32_t d0 = desc_of(0), d1 = desc_of(1), d2 = desc_of(2);
+                uint32_t ev = fetch(d0), ev1 = fetch(d1), ev2 = fetch(d2);
                 const pk2 so01 = {(short)so[0], (short)so[1]};
                 const pk2 so23 = {(short)so[2], (short)so[ENC_NC - 1]};
 #pragma unroll 1
-                while (todo) {
-                    todo &= todo - 1;
-                    const uint64_t t3 = t2 & (t2 - 1);
-                    const int r3 = row_of(t3, r2);
-                    const uint32_t ev3 = fetch(r3);
-                    const int b0 = r / 6, ch = r - 6 * b0;
-                    const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-                    const uint32_t starts = (uint32_t)((run_starts >> (8 * ch)) & 0x3f) | 0x40u;   // bit b: block b sends exponents
-                    const int b1 = __builtin_ctz(starts >> (b0 + 1)) + b0 + 1;
-                    const int16_t *Mr = &L.mask[r][0];
+                for (int i = 0; i < nrows; i++) {
+                    const uint32_t d3 = desc_of(i + 3);
+                    const uint32_t ev3 = fetch(d3);
+                    const int n = (d0 & (1u << 14)) ? 7 : nbc;
+                    const int16_t *Mr = &L.mask[d0 >> 24][0];
                     uint32_t sum[ENC_NC];
 #pragma unroll
                     for (int c = 0; c < ENC_NC; c++) sum[c] = 0;
@@ -1075,14 +1081,13 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                     }
 #pragma unroll
                     for (int B = 0; B < 6; B++) {
-                        const uint32_t in_run = (B >= b0 && B < b1) ? 1u : 0u;       // wave-uniform
+                        const uint32_t in_run = (d0 >> (16 + B)) & 1u;               // wave-uniform
 #pragma unroll
                         for (int k = 0; k < ENC_NC; k++)    // (written out: the compiler turns a multiply by 0/1 back into select + add)
                             asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[B][k]) : "v"(sum[k]), "s"(in_run));
                     }
-                    r = r1; r1 = r2; r2 = r3;
+                    d0 = d1; d1 = d2; d2 = d3;
                     ev = ev1; ev1 = ev2; ev2 = ev3;
-                    t2 = t3;
                 }
             }
             int total[ENC_NC];
@@ -1974,7 +1979,11 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     const unsigned nfr = (unsigned)E.n_streams * (unsigned)E.frames_per_stream;
     const bool long_streams = E.frames_per_stream > 1 && E.n_streams < 5120;
     const bool packb = E.pack_mode == 2 || (E.pack_mode == 0 && nfr <= 2048);
-    if (E.ws_snr && (packb || long_streams)) {
+    // Large batches of one-frame streams: search kernel (PART 1) + one wavefront per frame packs (PART 2) instead of the
+    // one-kernel PART 0, whose register budget holds neither half comfortably (128 VGPRs + scratch against 98 and 97).
+    // AC3MI_ENC_BIG_SPLIT=0: PART 0 (A/B runs).
+    static const int big_split = getenv("AC3MI_ENC_BIG_SPLIT") ? atoi(getenv("AC3MI_ENC_BIG_SPLIT")) : 1;
+    if (E.ws_snr && (packb || long_streams || big_split)) {
         P.memo = long_streams && E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
         if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3(nfr), dim3(64), 16, stream, P);
         hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 16, stream, P);
