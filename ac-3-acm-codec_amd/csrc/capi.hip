@@ -986,12 +986,13 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         HIPCHK(ctx, launch_xform(ctx->tab, X, ctx->stream));
         return AC3MI_OK;
     }
-    // A large batch goes through in two chunks of streams: the (HBM-bound) transform of chunk i runs on a
-    // second stream while the (instruction-bound) front end of chunk i+1 runs on the first.
     // One pass over the batch, kernels back to back on the context's stream.  Rounds 1-2 sent large batches through in two
     // chunks with the transform of chunk k on a second stream beside the front end of chunk k+1 (and round 3 tried the
     // mantissa kernel on a third): measured again with the split front end, 1 / 2 / 3 / 4 chunks = 3.545 / 3.549 / 3.572 /
     // 3.616 ms per 65 536 frames - a kernel of this size fills the chip, only the tails overlap - so the pipeline is gone.
+    // (Also tried in round 3: the batch in 2 / 4 / 8 / 16 tiles, front end + transform per tile, so that a tile's coefficient
+    // planes would still sit in the 256 MiB Infinity Cache when the transform reads them: 3.49 / 3.63 / 3.89 / 4.47 ms against
+    // 3.48 ms in one piece - each kernel's tail costs more than the cache gives.)
     const int n_chunks = 1;
     const size_t F = (size_t)frames_per_stream;
     for (int k = 0; k < n_chunks; k++) {

@@ -70,6 +70,8 @@ ALG = {
     "decode_wg_kernel<2>": 1536 + 18432 + 6144,
     "enc_mdct_kernel": 18432 + 6144,
     "enc_pack_kernel<0>": 1536,
+    "enc_pack_kernel<2>": 1536,
+    "enc_packb_kernel": 1536,
 }
 fetch = per_kernel("pmc_fetch/*counter_collection.csv", {"FETCH_SIZE"})
 write = per_kernel("pmc_write/*counter_collection.csv", {"WRITE_SIZE"})
@@ -113,7 +115,7 @@ def pick(*prefixes):
 legs = {
     "decode": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
     "decode_s16": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
-    "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>"),
+    "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>", "enc_pack_kernel<1>", "enc_pack_kernel<2>", "enc_packb_kernel"),
     "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>", "xform_kernel<true, 3, false>"),
 }
 legs["transcode"] = sorted(set(legs["decode_s16"]) | set(legs["encode"]))
