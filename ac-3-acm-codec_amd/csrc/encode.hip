@@ -1048,7 +1048,18 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             f_cc = (int)word(6);
         }
         bool went_down = false, went_up = false;
+        // Verdicts that follow from a costed offset WITHOUT costing: the frame's mantissa bits are (sum over coefficients of a
+        // nominal width: 0, 5/3, 7/3, 3, 7/2, 4, 5 ... 16 by bap) + (what the grouped codes' ceilings add: < 5 2/3 + 7 2/3 +
+        // 7 1/2 = 11.5 bits per block, < 69 per frame).  The nominal sum cannot fall when the offset rises (a coefficient's
+        // bap table address, :393-420, never falls with snroffset, and the widths rise with the address), so an offset that
+        // fails by more than 69 bits proves every higher one fails, and one that fits with more than 69 to spare proves every
+        // lower one fits - exactly, whatever the ceilings do.  Offsets as g = 16 csnroffst + fsnroffst.
+        constexpr int MARGIN = 72;
+        int fit_hi = -1, fail_lo = 1 << 20;
         auto lookup = [&](int cc, int ff, bool &fits) {
+            const int g = 16 * cc + ff;
+            if (g <= fit_hi) { fits = true; return true; }
+            if (g >= fail_lo) { fits = false; return true; }
             if (ff == 0) { fits = (fits_c >> cc) & 1; return (bool)((known_c >> cc) & 1); }
             fits = (fits_f >> ff) & 1;
             return cc == f_cc && ((known_f >> ff) & 1);
@@ -1125,6 +1136,9 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             }
             for (int i = 0; i < n_cand; i++) {
                 const bool ok = budget - total[i] >= 0;
+                const int g = 16 * cand_c[i] + cand_f[i];
+                if (budget - total[i] >= MARGIN && g > fit_hi) fit_hi = g;
+                if (budget - total[i] <= -MARGIN && g < fail_lo) fail_lo = g;
                 if (cand_f[i] == 0) { known_c |= 1ull << cand_c[i]; fits_c |= (uint64_t)ok << cand_c[i]; }
                 else {
                     if (cand_c[i] != f_cc) { f_cc = cand_c[i]; known_f = fits_f = 0; }     // costed ahead for another csnroffst
@@ -1133,6 +1147,8 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 }
             }
         };
+        bool first_sweep = true;
+        const bool cold_hint = csnr_prev == 40 && fsnr_prev == 0;          // the state AC3_encode_init leaves (a guess that only steers which offsets are costed first)
         for (;;) {
             // advance the reference's loop as far as the known verdicts reach
             int cc, ff;
@@ -1148,7 +1164,30 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
             // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
             int so[ENC_NC], cand_c[ENC_NC], cand_f[ENC_NC], n_cand = 0;
-            {
+            // Phase 0 of a search that has to come down a long way (a fresh stream starts at 40): the ladder csnroffst,
+            // csnroffst - 4, ... is probed at three points that cut its unknown stretch into quarters instead of walked three
+            // rungs per sweep - the bounds above turn a rung that fails or fits by a margin into the verdict of every rung
+            // beyond it.  (Which offsets are COSTED never changes a result: the reference's sequence is replayed from exact
+            // verdicts only.)
+            if (ss.phase == 0 && (went_down || (first_sweep && cold_hint))) {
+                int n = 0;
+                for (int c = ss.csnr; c >= 0 && n < 16; c -= 4, n++) { bool f; if (lookup(c, 0, f)) break; }
+                if (n > 3) {
+                    const int idx[3] = {(n - 1) / 4, (n - 1) / 2, (3 * (n - 1) + 2) / 4};
+                    for (int q = 0; q < 3; q++) {
+                        const int c = ss.csnr - 4 * idx[q];
+                        bool dup = false;
+                        for (int i = 0; i < n_cand; i++) dup = dup || cand_c[i] == c;
+                        if (dup) continue;
+                        const int v = ((c - 15) << 4) << 2;
+                        if (n_cand == 0) for (int k = 0; k < ENC_NC; k++) so[k] = v;
+                        cand_c[n_cand] = c; cand_f[n_cand] = 0;
+                        so[n_cand++] = v;
+                    }
+                }
+            }
+            first_sweep = false;
+            if (n_cand == 0) {
                 SnrSearch ahead = ss;
                 while (n_cand < ENC_NC && ahead.next(cc, ff)) {
                     bool fits;

@@ -39,3 +39,20 @@ for it in range(3):
     print("pass %d: %d frames, %.2f searches/frame" % (it, out[5], out[4] / n))
     for i, nm in enumerate(names):
         print("   %-30s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
+# second-generation content (the transcode's encoder half): the frames above decoded to s16, encoded from fresh state
+dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=enc.frame_bytes())
+delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+lfsr = torch.ones((S,), dtype=torch.int16, device=dev)
+s16, _ = eng.decode_s16_batch(dec, frames, delay, lfsr)
+eng.sync()
+last.zero_(); csnr.fill_(40)
+torch.cuda.synchronize()
+assert lib.ac3mi_debug_pack_cycles(out, 1) == 0
+eng.encode_batch(enc, s16.reshape(S, 1, 1536, 6), (0, 2, 1, 4, 5, 3), last, csnr, out=frames)
+torch.cuda.synchronize()
+assert lib.ac3mi_debug_pack_cycles(out, 1) == 0
+n = max(out[5], 1)
+tot = sum(out[i] for i in range(4))
+print("decoded content, cold: %d frame visits, %.2f searches/frame visit" % (out[5], out[4] / n))
+for i, nm in enumerate(names):
+    print("   %-30s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
