@@ -227,8 +227,9 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
 
             if (!err) do {
                 // ---- side information: parse.c:572-701 ----
-                for (int i = 0; i < nf; i++) blkswm |= rd.get(1) << i;
-                for (int i = 0; i < nf; i++) dithmask |= rd.get(1) << i;
+                // blksw[ch], dithflag[ch]: nf flags each, channel 0 first = in the field's top bit
+                blkswm = (int)(__builtin_bitreverse32(rd.get(nf)) >> (32 - nf));
+                dithmask = (int)(__builtin_bitreverse32(rd.get(nf)) >> (32 - nf));
                 int twice = !st.acmod, word = 0;
                 do {
                     if (rd.get(1)) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                 if (rd.get(1)) {                                            // cplstre
                     st.chincpl = 0;
                     if (rd.get(1)) {                                        // cplinu
-                        for (int i = 0; i < nf; i++) st.chincpl |= rd.get(1) << i;
+                        st.chincpl = (int)(__builtin_bitreverse32(rd.get(nf)) >> (32 - nf));
                         if (st.acmod < 2) { err = 1; break; }
                         if (st.acmod == 2) st.phsflginu = rd.get(1);
                         const int begf = rd.get(4), endf = rd.get(4);
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                 }
                 int cplexpstr = 0, lfeexpstr = 0, chexp = 0;   // chexp: 2 bits per channel
                 if (st.chincpl) cplexpstr = rd.get(2);
-                for (int i = 0; i < nf; i++) chexp |= rd.get(2) << (2 * i);
+                {                                               // chexpstr[ch]: nf two-bit codes, channel 0 first
+                    const uint32_t r = __builtin_bitreverse32(rd.get(2 * nf)) >> (32 - 2 * nf);       // channel order right, each code's bits swapped
+                    chexp = (int)(((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u));
+                }
                 if (st.lfeon) lfeexpstr = rd.get(1);
                 if (blk == 0) {
                     if (st.chincpl && !cplexpstr) reuse0 = true;
@@ -814,7 +818,8 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
         M.lfeon = L.lfeon;
         M.n_in = P.n_in;
         M.nfchans = P.nfchans;
-        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4, stream, M);
+        static const int mant_pad = getenv("AC3MI_MANT_LDS_PAD") ? atoi(getenv("AC3MI_MANT_LDS_PAD")) : 0;      // profiling aid: occupancy proxy of a fused mantissa + transform workgroup
+        hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + mant_pad, stream, M);
         return hipGetLastError();
     }
     if (!L.frame_parallel) {
