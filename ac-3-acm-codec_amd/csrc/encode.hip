@@ -1368,31 +1368,61 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 uint32_t baseg = 0, basem = 0;      // the same as (codes opened mod 256) << 8 kind and (members of the open code) << 2 kind
                 int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
                 uint32_t *const sink = &L.gtab[512 + 2 * lane];
+                // The LFE's seven coefficients ride in the LAST full-bandwidth channel's pass: that channel's 223 bins fill
+                // lanes 0..55, lane 56 + k takes LFE bin k in its first slot - lane order is bitstream order (the LFE follows
+                // the last channel, :1334-1502), so ranks, offsets and grouped codes come out as from a pass of its own, which
+                // would cost as much as a full channel's.
+                const bool lfe_rides = P.lfe && nch >= 2 && nbc <= 224;
+                const int npass = lfe_rides ? nch - 1 : nch;
+                const int lk = lane - 56;                                   // the LFE bin of this lane in the merged pass
+                int lfe_c = 0;
+                if (lfe_rides && lk >= 0 && lk < 7) lfe_c = mdb[(nch - 1) * 256 + lk];
 #pragma unroll 1
-                for (int ch = 0; ch < nch; ch++) {
-                    const int4 c4 = nx_c;
+                for (int ch = 0; ch < npass; ch++) {
+                    int4 c4 = nx_c;
                     uint32_t e4 = 0;
 #pragma unroll
                     for (int c2 = 0; c2 < 6; c2++) e4 = c2 == ch ? ew[c2] : e4;
                     {
-                        const int nc = ch + 1 < nch ? ch + 1 : ch;          // the next channel's coefficients are in flight meanwhile
+                        const int nc = ch + 1 < npass ? ch + 1 : ch;        // the next channel's coefficients are in flight meanwhile
                         nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
                     }
-                    const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
+                    const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
+                    const bool lfe_lane = merged && lk >= 0;
                     const int16_t *Mr = &L.mask[b * 6 + ch][0];
-                    const int shv = (int)L.shiftv[b * 6 + ch];
+                    int shv = (int)L.shiftv[b * 6 + ch];
+                    uint32_t bands = bandoff;
+                    if (merged) {
+                        uint32_t le = 0;
+#pragma unroll
+                        for (int c2 = 0; c2 < 6; c2++) le = c2 == nch - 1 ? ew[c2] : le;
+                        const uint32_t lexp = ((uint32_t)__shfl((int)le, lk >= 0 ? lk >> 2 : 0, 64) >> (8 * (lk & 3))) & 0xffu;
+                        e4 = lfe_lane ? lexp : e4;
+                        c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
+                        Mr = lfe_lane ? &L.mask[b * 6 + nch - 1][0] : Mr;
+                        shv = lfe_lane ? (int)L.shiftv[b * 6 + nch - 1] : shv;
+                        bands = lfe_lane ? (uint32_t)lk : bands;              // (LFE bins 0..6 are bands 0..6)
+                    }
                     const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
                     uint32_t pw[4], cnt_lane = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int xe = (int)((e4 >> (8 * j)) & 0xff), m = Mr[(bandoff >> (8 * j)) & 0xff];
-                        const int d4 = 4 * lane + j < n ? 320 - 16 * xe : -(1 << 20);
+                        const int xe = (int)((e4 >> (8 * j)) & 0xff), m = Mr[(bands >> (8 * j)) & 0xff];
+                        const bool coded = lfe_lane ? (j == 0 && lk < 7) : (4 * lane + j < ((!lfe_rides && P.lfe && ch == nch - 1) ? 7 : nbc));
+                        const int d4 = coded ? 320 - 16 * xe : -(1 << 20);
                         pw[j] = L.packlut[lut_index(d4, m, snroffset)];
                         cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
                     }
-                    if (P.tap_bap)
-                        *reinterpret_cast<uint32_t *>(P.tap_bap + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) =
-                            ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                    if (P.tap_bap) {
+                        uint8_t *tb = P.tap_bap + ((fidx * 6 + b) * nch + ch) * 256;
+                        const uint32_t four = ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                        *reinterpret_cast<uint32_t *>(tb + 4 * lane) = lfe_lane ? 0u : four;
+                        if (merged) {                                       // the LFE's row: bins 0..6 from lanes 56..62, zeros beyond
+                            uint8_t *tl = P.tap_bap + ((fidx * 6 + b) * nch + nch - 1) * 256;
+                            if (lane >= 2) *reinterpret_cast<uint32_t *>(tl + 4 * lane) = 0u;
+                            if (lfe_lane) tl[lk] = (uint8_t)(lk < 7 ? (pw[0] >> 20) & 15u : 0u);
+                        }
+                    }
                     const uint32_t gin = wave_incl_scan_u32(cnt_lane);
                     uint32_t run = gin - cnt_lane;                          // ranks inside the pass of the lane's next bin, per kind
                     uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
@@ -1764,17 +1794,37 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
             uint32_t baseg = 0, basem = 0;
             int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
             uint32_t *const sink = &W.gtab[512 + 2 * lane];
+            // the LFE's seven coefficients ride in the last full-bandwidth channel's pass (lanes 56..62): see enc_pack_kernel
+            const bool lfe_rides = P.lfe && nch >= 2 && nbc <= 224;
+            const int npass = lfe_rides ? nch - 1 : nch;
+            const int lk = lane - 56;
+            int lfe_c = 0;
+            if (lfe_rides && lk >= 0 && lk < 7) lfe_c = mdb[(nch - 1) * 256 + lk];
 #pragma unroll 1
-            for (int ch = 0; ch < nch; ch++) {
-                const int4 c4 = nx_c;
+            for (int ch = 0; ch < npass; ch++) {
+                int4 c4 = nx_c;
                 uint32_t e4 = 0, a4 = 0;
 #pragma unroll
                 for (int c2 = 0; c2 < 6; c2++) { e4 = c2 == ch ? ew[c2] : e4; a4 = c2 == ch ? ad[c2] : a4; }
                 {
-                    const int nc = ch + 1 < nch ? ch + 1 : ch;          // the next channel's coefficients are in flight meanwhile
+                    const int nc = ch + 1 < npass ? ch + 1 : ch;        // the next channel's coefficients are in flight meanwhile
                     nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
                 }
-                const int shv = __builtin_amdgcn_readlane(shift_l, ch);
+                const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
+                const bool lfe_lane = merged && lk >= 0;
+                int shv = __builtin_amdgcn_readlane(shift_l, ch);
+                if (merged) {
+                    uint32_t le = 0, la = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < 6; c2++) { le = c2 == nch - 1 ? ew[c2] : le; la = c2 == nch - 1 ? ad[c2] : la; }
+                    const int srcl = lk >= 0 ? lk >> 2 : 0;
+                    const uint32_t lexp = ((uint32_t)__shfl((int)le, srcl, 64) >> (8 * (lk & 3))) & 0xffu;
+                    const uint32_t ladr = ((uint32_t)__shfl((int)la, srcl, 64) >> (8 * (lk & 3))) & 63u;
+                    e4 = lfe_lane ? lexp : e4;
+                    a4 = lfe_lane ? (lk < 7 ? ladr : 0u) : a4;              // (address 0: bap 0, no bits - the lane's other three slots)
+                    c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
+                    shv = lfe_lane ? __builtin_amdgcn_readlane(shift_l, nch - 1) : shv;
+                }
                 const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
                 uint32_t pw[4], cnt_lane = 0;
 #pragma unroll
@@ -1782,9 +1832,16 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
                     pw[j] = L.packlut[(a4 >> (8 * j)) & 63u];
                     cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
                 }
-                if (P.tap_bap)
-                    *reinterpret_cast<uint32_t *>(P.tap_bap + (rowb + ch) * 256 + 4 * lane) =
-                        ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                if (P.tap_bap) {
+                    uint8_t *tb = P.tap_bap + (rowb + ch) * 256;
+                    const uint32_t four = ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
+                    *reinterpret_cast<uint32_t *>(tb + 4 * lane) = lfe_lane ? 0u : four;
+                    if (merged) {
+                        uint8_t *tl = P.tap_bap + (rowb + nch - 1) * 256;
+                        if (lane >= 2) *reinterpret_cast<uint32_t *>(tl + 4 * lane) = 0u;
+                        if (lfe_lane) tl[lk] = (uint8_t)(lk < 7 ? (pw[0] >> 20) & 15u : 0u);
+                    }
+                }
                 const uint32_t gin = wave_incl_scan_u32(cnt_lane);
                 uint32_t run = gin - cnt_lane;
                 uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
