@@ -563,8 +563,6 @@ __device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int
 #endif
 __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctParams P)
 {
-    __shared__ int16_t in[512];
-    __shared__ c16 z[128];
     __shared__ int32_t out[256];
     __shared__ ExpLDS XL;
 
@@ -583,21 +581,32 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
     const int f = sf % P.frames;
     const int s = sf / P.frames;
 
-    // the window values this lane ever needs (samples lane + 64k of either half): registers, not LDS
+    // Which samples a lane owns.  Point i of the pre-rotation (:578-591) takes four samples of the 512 windowed ones:
+    //   i < 64 :  re <- -in[384 + 2i], in[383 - 2i]     im <- in[128 + 2i], in[127 - 2i]
+    //   i >= 64:  re <-  in[2i - 128], in[383 - 2i]     im <- in[128 + 2i], -in[639 - 2i]
+    // so a lane that holds positions {2L, 127 - 2L, 128 + 2L, 255 - 2L} of the old AND of the new half has every operand of
+    // the points L and L + 64 in its own registers; and with L = the lane number's six bits reversed those two points are
+    // the ones the bit-reversed order (:496-504) puts at 2 lane and 2 lane + 1: its first butterfly.  Windowing, block floating
+    // point, rotation and the reordering then need no LDS at all (same operands, same 16-bit truncations).
+    const int L = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);
+    const int jpos[4] = {2 * L, 127 - 2 * L, 128 + 2 * L, 255 - 2 * L};
     int wa[4], wb[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { wa[k] = P.tab->win[lane + 64 * k]; wb[k] = P.tab->win[255 - lane - 64 * k]; }
+    for (int k = 0; k < 4; k++) { wa[k] = P.tab->win[jpos[k]]; wb[k] = P.tab->win[255 - jpos[k]]; }
     for (int i = lane; i < 256; i += 64) {
         XL.t.latab[i] = P.tab->latab[i];
         XL.t.band_of_bin[i] = P.tab->band_of_bin[i];
     }
     if (lane < 50) XL.t.hth[lane] = P.tab->hth[lane][P.x.fscod];
     if (lane < 52) XL.t.band_start[lane] = lane < 51 ? P.tab->band_start[lane] : 0;
-    // rotation factors and bit-reversed places of the lane's two points i = lane, lane + 64 (:578-591, :496-504), and the
-    // twiddles of its butterfly in passes 2..6 (:533-567: twiddle index (lane mod nloops) * nblocks): constant per lane
-    int xcv[2], xsv[2], revv[2], twc[5], tws[5];
+    // rotation factors of the points the lane rotates BEFORE the passes (L, L + 64) and AFTER them (lane, lane + 64; :596-602),
+    // and the twiddles of its butterfly in passes 2..6 (:533-567: twiddle index (lane mod nloops) * nblocks): constant per lane
+    int xcv[2], xsv[2], pcv[2], psv[2], twc[5], tws[5];
 #pragma unroll
-    for (int k = 0; k < 2; k++) { xcv[k] = P.tab->xcos[lane + 64 * k]; xsv[k] = P.tab->xsin[lane + 64 * k]; revv[k] = P.tab->bitrev[lane + 64 * k]; }
+    for (int k = 0; k < 2; k++) {
+        xcv[k] = P.tab->xcos[lane + 64 * k]; xsv[k] = P.tab->xsin[lane + 64 * k];
+        pcv[k] = -P.tab->xcos[L + 64 * k]; psv[k] = P.tab->xsin[L + 64 * k];
+    }
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int nloops = 4 << k, nblocks = 16 >> k, m = lane & (nloops - 1);
@@ -606,12 +615,12 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
     }
 
     const int16_t *frame_pcm = P.pcm + ((size_t)s * P.frames + f) * 1536 * P.nch + P.chmap[ch];
-    // samples lane, 64+lane, 128+lane, 192+lane of: the block before (history), this block, and - in flight while
-    // this block is transformed - the next one.  Every sample is read from HBM once.
+    // the lane's four samples of: the block before (history), this block, and - in flight while this block is
+    // transformed - the next one.  Every sample is read from HBM once.
     int16_t oldv[4], newv[4], nxtv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int j = lane + 64 * k;
+        const int j = jpos[k];
         if (f > 0) oldv[k] = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];         // block 5 of the previous frame
         else oldv[k] = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
         newv[k] = frame_pcm[(size_t)j * P.nch];
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
         int win_[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int j = lane + 64 * k;
+            const int j = jpos[k];
             nxtv[k] = blk < 5 ? frame_pcm[(size_t)((blk + 1) * 256 + j) * P.nch] : (int16_t)0;
             if (P.store_history && blk == 5) {
                 if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
@@ -639,32 +648,23 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
         int v = 14 - ilog2u((unsigned)acc);
         if (v < 0) v = 0;
         const int shift = v - 9;
+        int O[4], N[4];                                                     // in[jpos[k]], in[256 + jpos[k]] as 16-bit values
 #pragma unroll
-        for (int k = 0; k < 8; k++) in[lane + 64 * k] = (int16_t)(win_[k] * (1 << v));
-        WAVE_SYNC();
-        // ---- rotation + pre-rotation (:578-591), stored bit-reversed (:496-504) ----
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = lane + 64 * k;
-            auto rot = [&](int t) -> int { return t < 128 ? (int)(int16_t)(-in[t + 384]) : (int)in[t - 128]; };
-            const int re = (rot(2 * i) - rot(511 - 2 * i)) >> 1;
-            const int im = (-(rot(256 + 2 * i) - rot(255 - 2 * i))) >> 1;
-            const int c = -xcv[k], sx = xsv[k];
-            c16 t;
-            t.re = (int16_t)((re * c - im * sx) >> 15);
-            t.im = (int16_t)((re * sx + c * im) >> 15);
-            z[revv[k]] = t;
+        for (int k = 0; k < 4; k++) { O[k] = (int16_t)(win_[k] * (1 << v)); N[k] = (int16_t)(win_[4 + k] * (1 << v)); }
+        // ---- rotation + pre-rotation (:578-591) of the points L (-> p) and L + 64 (-> q) ----
+        int pr, pi, qr, qi;
+        {
+            const int re0 = ((int)(int16_t)(-N[2]) - N[1]) >> 1, im0 = (-(O[2] - O[1])) >> 1;
+            const int re1 = (O[0] - O[3]) >> 1, im1 = (-(N[0] - (int)(int16_t)(-N[3]))) >> 1;
+            pr = (int16_t)((re0 * pcv[0] - im0 * psv[0]) >> 15);
+            pi = (int16_t)((re0 * psv[0] + pcv[0] * im0) >> 15);
+            qr = (int16_t)((re1 * pcv[1] - im1 * psv[1]) >> 15);
+            qi = (int16_t)((re1 * psv[1] + pcv[1] * im1) >> 15);
         }
-        WAVE_SYNC();
         // ---- the seven passes (:508-567) in registers: the lane's butterfly of pass k takes the points ip = (lane / d) 2d +
         //      lane mod d and ip + d (d = 2^k); between two passes every lane trades ONE point with lane ^ d (the upper half of
         //      a 2d-lane group gives its first point and keeps the second, the lower half the other way round).  Same operands,
         //      shifts and 16-bit truncations as the reference's in-place loops, no LDS round trip per pass. ----
-        int pr, pi, qr, qi;
-        {
-            const c16 p0 = z[2 * lane], q0 = z[2 * lane + 1];
-            pr = p0.re; pi = p0.im; qr = q0.re; qi = q0.im;
-        }
         auto bfly_r = [&](int ax, int ay) {
             const int bx = pr, by = pi;
             pr = (int16_t)((bx + ax) >> 1);
