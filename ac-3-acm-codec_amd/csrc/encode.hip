@@ -267,59 +267,76 @@ __device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
 // ---------------------------------------------------------------------------------------------
 // Wavefront-wide versions of the two routines above for exp_stage (same results).
 
-// encode_exp on one row: entry i = 1 + 64c + lane of chunk c.  min over j of g[j] + 2|i-j| is a prefix minimum of
-// g[j] - 2j (ascending) followed by a suffix minimum of g[j] + 2j (descending).
+// per byte (values < 128): b's byte where it is smaller and `where` selects the byte, else a's
+__device__ __forceinline__ uint32_t bytes_min_where(uint32_t a, uint32_t b, uint32_t where)
+{
+    const uint32_t ge = (((a | 0x80808080u) - b) >> 7) & 0x01010101u;       // 1: a >= b (no borrow crosses a byte)
+    const uint32_t m = (ge * 0xffu) & where;
+    return (b & m) | (a & ~m);
+}
+
+// encode_exp (:684-761) on one 256-byte row in LDS, a dword per lane.  Lane l takes bins 4l+1 .. 4l+4: four entries for D15,
+// two for D25, one for D45 (entry i covers bins 1 + (i-1) gs .. + gs-1, so groups never straddle lanes).  The +-2 delta
+// constraint, min over j of g[j] + 2|i-j|, is a prefix minimum of g[j] - 2j followed by a suffix minimum of g[j] + 2j: inside
+// the lane first, then ONE scan over the lane totals per direction.
 __device__ int encode_exp_wave(uint8_t *row, int n, int strategy, int lane)
 {
     constexpr int INF = 0x3fffffff;
     const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
+    const int per = strategy == 1 ? 4 : strategy == 2 ? 2 : 1;             // entries per lane
     const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
-    int row0 = row[0];
+    uint32_t *q = reinterpret_cast<uint32_t *>(row);
+    const uint32_t own = q[lane], nxt = q[lane + 1];        // lane 63 reads the dword behind the row: entries beyond ng, never used
+    const uint32_t S = __builtin_amdgcn_alignbyte(nxt, own, 1u);
+    const int b0 = (int)(S & 0xffu), b1 = (int)((S >> 8) & 0xffu), b2 = (int)((S >> 16) & 0xffu), b3 = (int)(S >> 24);
+    const int m01 = b1 < b0 ? b1 : b0, m23 = b3 < b2 ? b3 : b2, m03 = m23 < m01 ? m23 : m01;
+    int row0 = (int)(__builtin_amdgcn_readfirstlane((int)own) & 0xff);
     row0 = row0 > 15 ? 15 : row0;
-    int g[4];
+    int g[4], ix[4];
+    bool valid[4];
+    g[0] = per == 4 ? b0 : per == 2 ? m01 : m03;
+    g[1] = per == 4 ? b1 : m23;
+    g[2] = b2;
+    g[3] = b3;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const int i = 1 + 64 * c + lane;
-        const int k = 1 + (i - 1) * gs;
-        int x = INF;
-        if (i <= ng) {
-            x = row[k];
-            if (gs >= 2) { const int y = row[k + 1]; x = y < x ? y : x; }
-            if (gs == 4) { const int y = row[k + 2], z = row[k + 3]; x = y < x ? y : x; x = z < x ? z : x; }
-        }
-        g[c] = x;
+        ix[c] = 2 * (per * lane + 1 + c);
+        valid[c] = c < per && per * lane + 1 + c <= ng;
     }
-    int carry = row0;
+    int t[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        if (64 * c >= ng) continue;
-        const int i = 1 + 64 * c + lane;
-        int s = wave_incl_scan_min(i <= ng ? g[c] - 2 * i : INF);
-        s = s < carry ? s : carry;
-        carry = __builtin_amdgcn_readlane(s, 63);
-        g[c] = i <= ng ? s + 2 * i : INF;
+        const int a = valid[c] ? g[c] - ix[c] : INF;
+        t[c] = c == 0 ? a : (a < t[c - 1] ? a : t[c - 1]);
     }
-    carry = INF;
+    {
+        int ex = __builtin_amdgcn_update_dpp(INF, wave_incl_scan_min(t[3]), 0x138, 0xf, 0xf, false);       // wave_shr:1
+        ex = row0 < ex ? row0 : ex;
+#pragma unroll
+        for (int c = 0; c < 4; c++) g[c] = (t[c] < ex ? t[c] : ex) + ix[c];
+    }
 #pragma unroll
     for (int c = 3; c >= 0; c--) {
-        if (64 * c >= ng) continue;
-        const int i = 1 + 64 * c + lane;
-        int s = wave_suffix_scan_min(i <= ng ? g[c] + 2 * i : INF, lane);
-        s = s < carry ? s : carry;
-        carry = __builtin_amdgcn_readlane(s, 0);
-        g[c] = s - 2 * i;
+        const int a = valid[c] ? g[c] + ix[c] : INF;
+        t[c] = c == 3 ? a : (a < t[c + 1] ? a : t[c + 1]);
     }
+    const int suf = wave_suffix_scan_min(t[0], lane);
+    {
+        const int ex = __builtin_amdgcn_update_dpp(INF, suf, 0x130, 0xf, 0xf, false);                       // wave_shl:1
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int i = 1 + 64 * c + lane;
-        const int k = 1 + (i - 1) * gs;
-        if (i <= ng) {
-            row[k] = (uint8_t)g[c];
-            if (gs >= 2) row[k + 1] = (uint8_t)g[c];
-            if (gs == 4) { row[k + 2] = (uint8_t)g[c]; row[k + 3] = (uint8_t)g[c]; }
-        }
+        for (int c = 0; c < 4; c++) g[c] = (t[c] < ex ? t[c] : ex) - ix[c];
     }
-    if (lane == 0) row[0] = (uint8_t)(carry < row0 ? carry : row0);
+    const int head = __builtin_amdgcn_readfirstlane(suf);
+    const int row0new = head < row0 ? head : row0;
+    // back to bins (entries beyond ng leave their bins alone)
+    const int e1 = per == 4 ? 1 : 0, e2 = per == 4 ? 2 : per == 2 ? 1 : 0, e3 = per == 4 ? 3 : per == 2 ? 1 : 0;
+    const int g1 = e1 ? g[1] : g[0], g2 = e2 == 2 ? g[2] : e2 == 1 ? g[1] : g[0], g3 = e3 == 3 ? g[3] : e3 == 1 ? g[1] : g[0];
+    const bool v1 = e1 ? valid[1] : valid[0], v2 = e2 == 2 ? valid[2] : e2 == 1 ? valid[1] : valid[0];
+    const bool v3 = e3 == 3 ? valid[3] : e3 == 1 ? valid[1] : valid[0];
+    const uint32_t o = (uint32_t)(valid[0] ? g[0] : b0) | (uint32_t)(v1 ? g1 : b1) << 8 | (uint32_t)(v2 ? g2 : b2) << 16 |
+                       (uint32_t)(v3 ? g3 : b3) << 24;
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(row0new << 24, (int)o, 0x138, 0xf, 0xf, false);
+    q[lane] = __builtin_amdgcn_alignbyte(o, prev, 3u);
     return 4 + (ng / 3) * 7;
 }
 
@@ -389,11 +406,22 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
 #pragma unroll
     for (int b = 0; b < 6; b++) raw[b] = *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
 
-    // ---- exponent strategy (:617-669): sum of |differences| over all 256 bins against the block before ----
+    // ---- exponent strategy (:617-669): sum of |differences| over all 256 bins against the block before (two sums per
+    //      reduction: each stays below 2^16) ----
     int st[6];
     st[0] = 1;
+    {
+        const uint32_t d1 = __builtin_amdgcn_sad_u8(raw[1], raw[0], 0u), d2 = __builtin_amdgcn_sad_u8(raw[2], raw[1], 0u);
+        const uint32_t d3 = __builtin_amdgcn_sad_u8(raw[3], raw[2], 0u), d4 = __builtin_amdgcn_sad_u8(raw[4], raw[3], 0u);
+        const uint32_t d5 = __builtin_amdgcn_sad_u8(raw[5], raw[4], 0u);
+        const uint32_t t12 = wave_sum_u32(d1 | d2 << 16), t34 = wave_sum_u32(d3 | d4 << 16), t5 = wave_sum_u32(d5);
+        st[1] = (t12 & 0xffffu) > 1000u; st[2] = (t12 >> 16) > 1000u;
+        st[3] = (t34 & 0xffffu) > 1000u; st[4] = (t34 >> 16) > 1000u;
+        st[5] = t5 > 1000u;
+    }
+    uint32_t starts = 0;                                        // bit b: block b sends exponents (wave-uniform)
 #pragma unroll
-    for (int b = 1; b < 6; b++) st[b] = wave_sum((int)__builtin_amdgcn_sad_u8(raw[b], raw[b - 1], 0u)) > 1000 ? 1 : 0;
+    for (int b = 0; b < 6; b++) starts |= (st[b] != 0 ? 1u : 0u) << b;
     if (!is_lfe) {
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -408,48 +436,46 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
 #pragma unroll
         for (int b = 0; b < 6; b++) L.strat[b] = (uint8_t)st[b];
     }
-    WAVE_SYNC();
 
-    // ---- min-merge over reuse runs (:1731-1737), lanes over bins ----
+    // ---- min-merge over reuse runs (:1731-1737), bins below n only: in registers, four bins per lane ----
     {
-        int b = 0;
-        while (b < 6) {
-            int e = b + 1;
-            while (e < 6 && L.strat[e] == 0) {
-                for (int j = lane; j < n; j += 64) {
-                    const uint8_t x = L.E[e][j];
-                    if (x < L.E[b][j]) L.E[b][j] = x;
-                }
-                e++;
+        uint32_t below = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) below |= (4 * lane + c < n ? 0xffu : 0u) << (8 * c);
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+            if (!((starts >> b) & 1u)) continue;
+            bool open = true;
+            bool touched = false;
+#pragma unroll
+            for (int e = b + 1; e < 6; e++) {
+                open = open && !((starts >> e) & 1u);
+                if (open) { raw[b] = bytes_min_where(raw[b], raw[e], below); touched = true; }
             }
-            b = e;
+            if (touched) *reinterpret_cast<uint32_t *>(&L.E[b][4 * lane]) = raw[b];
         }
     }
     WAVE_SYNC();
 
-    // ---- encode_exp on run starts, then replicate (:1739-1746) ----
+    // ---- encode_exp on run starts (:1739-1746); the blocks of a run are sent the start's exponents ----
     int exp_bits = 0;
-    for (int b = 0; b < 6; b++) {
-        const int stg = L.strat[b];
-        if (stg != 0) exp_bits += encode_exp_wave(L.E[b], n, stg, lane);
+    for (uint32_t m = starts; m; m &= m - 1) {
+        const int b = __builtin_ctz(m);
+        exp_bits += encode_exp_wave(L.E[b], n, L.strat[b], lane);
     }
     WAVE_SYNC();
     {
-        int src = 0;
-        for (int b = 1; b < 6; b++) {
-            if (L.strat[b] != 0) { src = b; continue; }
-            for (int j = lane; j < n; j += 64) L.E[b][j] = L.E[src][j];
+        uint32_t cur = 0;
+        for (int b = 0; b < 6; b++) {
+            if ((starts >> b) & 1u) cur = *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
+            *reinterpret_cast<uint32_t *>(P.eexp + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) = cur;
         }
     }
-    WAVE_SYNC();
 
     // ---- band PSDs (:220-258) and masking curves (:259-367) of the blocks that send exponents; a block that
     //      reuses them has the same curve.  Bands 0..27 are single bins; the 22 wider ones are integrated by
     //      one lane each, two rows per sweep ----
     {
-        uint32_t starts = 0;                                        // bit b: block b sends exponents (wave-uniform)
-#pragma unroll
-        for (int b = 0; b < 6; b++) starts |= (st[b] != 0 ? 1u : 0u) << b;
         const int nsingle = n < 28 ? n : 28;
         for (uint32_t m = starts; m; m &= m - 1) {
             const int r = __builtin_ctz(m);
@@ -509,23 +535,28 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
         const int bndend = L.t.band_of_bin[n - 1] + 1;
         for (uint32_t m = starts; m; m &= m - 1)
             mask_row_wave(L.t, L.mask[__builtin_ctz(m)], bndend, is_lfe, sdecay, fdecay, sgain, dbknee, fgain, P.halfrate, lane);
-        WAVE_SYNC();
-        for (int b = 1, src = 0; b < 6; b++) {
-            if ((starts >> b) & 1) { src = b; continue; }
-            if (lane < 50) L.mask[b][lane] = L.mask[src][lane];
-        }
     }
     WAVE_SYNC();
 
-    // ---- results: the pack kernel wants the masks minus the floor (floorcod 4: 0x1f0) ----
+    // ---- results: the pack kernel wants the masks minus the floor (floorcod 4: 0x1f0); a block inside a run has its start's
+    //      curve.  Two rows of 25 dwords per step ----
     static_assert(enc_floor(4) == 0x1f0 && enc_sgain(1) == 0x4d8 && enc_dbknee(2) == 0x900, "ENC/ac3tab.h:151-161");
+    {
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        const int half = lane >= 25 ? 1 : 0, k2 = lane - 25 * half;
+        int src[6];
+        src[0] = 0;
 #pragma unroll
-    for (int b = 0; b < 6; b++)
-        *reinterpret_cast<uint32_t *>(P.eexp + ((fidx * 6 + b) * nch + ch) * 256 + 4 * lane) =
-            *reinterpret_cast<const uint32_t *>(&L.E[b][4 * lane]);
-    for (int i = lane; i < 6 * 50; i += 64) {
-        const int b = i / 50, k = i - 50 * b;
-        P.emask[((fidx * 6 + b) * nch + ch) * 50 + k] = (int16_t)(L.mask[b][k] - enc_floor(4));
+        for (int b = 1; b < 6; b++) src[b] = ((starts >> b) & 1u) ? b : src[b - 1];
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int b = 2 * it + half, sr = half ? src[2 * it + 1] : src[2 * it];
+            if (lane < 50) {
+                short2v v = *reinterpret_cast<const short2v *>(&L.mask[sr][2 * k2]);
+                v -= (short2v){(short)enc_floor(4), (short)enc_floor(4)};
+                *reinterpret_cast<short2v *>(P.emask + ((fidx * 6 + b) * nch + ch) * 50 + 2 * k2) = v;
+            }
+        }
     }
     if (lane < 6) P.strat[(fidx * 6 + lane) * nch + ch] = L.strat[lane];
     if (lane == 0) P.ebits[fidx * nch + ch] = exp_bits;
