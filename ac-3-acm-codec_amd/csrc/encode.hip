@@ -1087,10 +1087,19 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
         // lower one fits - exactly, whatever the ceilings do.  Offsets as g = 16 csnroffst + fsnroffst.
         constexpr int MARGIN = 72;
         int fit_hi = -1, fail_lo = 1 << 20;
+        // Every offset costed for this frame, whether the reference asks for it or not: 1024-bit maps "costed" / "fits", word w in
+        // lane w of one register each; and the two costed offsets that enclose the boundary most closely, with their spare bits.
+        uint32_t costed_map = 0, fits_map = 0;
+        int gl = -1, spare_l = 0, gh = -1, spare_h = 0;
+        int probe_sweeps = 0;
         auto lookup = [&](int cc, int ff, bool &fits) {
             const int g = 16 * cc + ff;
             if (g <= fit_hi) { fits = true; return true; }
             if (g >= fail_lo) { fits = false; return true; }
+            if (((uint32_t)__builtin_amdgcn_readlane((int)costed_map, g >> 5) >> (g & 31)) & 1u) {
+                fits = ((uint32_t)__builtin_amdgcn_readlane((int)fits_map, g >> 5) >> (g & 31)) & 1u;
+                return true;
+            }
             if (ff == 0) { fits = (fits_c >> cc) & 1; return (bool)((known_c >> cc) & 1); }
             fits = (fits_f >> ff) & 1;
             return cc == f_cc && ((known_f >> ff) & 1);
@@ -1099,8 +1108,11 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
         // is a function of the (encoded) exponents alone, so a block that reuses a channel's exponents has that
         // channel's counts of the block that sent them: every run of blocks is counted once, 64 bins per step, and
         // added to the per-lane accumulators of all blocks of the run.
-        auto cost_and_record = [&](const int *so, const int *cand_c, const int *cand_f, int n_cand) {
+        auto cost_and_record = [&](const int (&cg)[ENC_NC], int n_cand, bool probing) {
             if (!loaded) load_frame();
+            int so[ENC_NC];                 // snroffset (:393-420) of the candidates; unused slots repeat the first
+#pragma unroll
+            for (int k = 0; k < ENC_NC; k++) so[k] = ((k < n_cand ? cg[k] : cg[0]) - 240) << 2;
             PK_COUNT(4);
             const int budget = 16 * fs - frame_bits;
             uint32_t acc[6][ENC_NC];
@@ -1165,16 +1177,29 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                     total[c] += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
                 }
             }
-            for (int i = 0; i < n_cand; i++) {
-                const bool ok = budget - total[i] >= 0;
-                const int g = 16 * cand_c[i] + cand_f[i];
-                if (budget - total[i] >= MARGIN && g > fit_hi) fit_hi = g;
-                if (budget - total[i] <= -MARGIN && g < fail_lo) fail_lo = g;
-                if (cand_f[i] == 0) { known_c |= 1ull << cand_c[i]; fits_c |= (uint64_t)ok << cand_c[i]; }
-                else {
-                    if (cand_c[i] != f_cc) { f_cc = cand_c[i]; known_f = fits_f = 0; }     // costed ahead for another csnroffst
-                    known_f |= 1u << cand_f[i];
-                    fits_f |= (uint32_t)ok << cand_f[i];
+#pragma unroll
+            for (int i = 0; i < ENC_NC; i++) {
+                if (i >= n_cand) break;
+                const int spare = budget - total[i];
+                const bool ok = spare >= 0;
+                const int g = cg[i], cand_ci = g >> 4, cand_fi = g & 15;
+                if (spare >= MARGIN && g > fit_hi) fit_hi = g;
+                if (spare <= -MARGIN && g < fail_lo) fail_lo = g;
+                {
+                    const uint32_t bit = lane == (g >> 5) ? 1u << (g & 31) : 0u;
+                    costed_map |= bit;
+                    fits_map |= ok ? bit : 0u;
+                }
+                {                                   // (selects: an if / else here makes hipcc keep the four in scratch)
+                    const bool up = ok && g > gl, dn = !ok && (gh < 0 || g < gh);
+                    gl = up ? g : gl; spare_l = up ? spare : spare_l;
+                    gh = dn ? g : gh; spare_h = dn ? spare : spare_h;
+                }
+                if (cand_fi == 0) { known_c |= 1ull << cand_ci; fits_c |= (uint64_t)ok << cand_ci; }
+                else if (!probing || cand_ci == f_cc) {
+                    if (cand_ci != f_cc) { f_cc = cand_ci; known_f = fits_f = 0; }     // costed ahead for another csnroffst
+                    known_f |= 1u << cand_fi;
+                    fits_f |= (uint32_t)ok << cand_fi;
                 }
             }
         };
@@ -1194,27 +1219,51 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             if (!more) break;
             // up to three offsets not costed yet, along the likeliest continuation: the start value fits unless
             // an earlier one did not, +4 steps fail unless one has fitted, the finer steps fit
-            int so[ENC_NC], cand_c[ENC_NC], cand_f[ENC_NC], n_cand = 0;
+            // (candidates as g = 16 csnroffst + fsnroffst in a list written through static indices only: a dynamic index sends
+            // such arrays to scratch)
+            int cg[ENC_NC], n_cand = 0;
+#pragma unroll
+            for (int k = 0; k < ENC_NC; k++) cg[k] = -1;
+            auto add = [&](int g) {                 // false: already in the list
+                bool dup = false;
+#pragma unroll
+                for (int k = 0; k < ENC_NC; k++) dup = dup || cg[k] == g;
+                if (dup) return false;
+#pragma unroll
+                for (int k = 0; k < ENC_NC; k++) cg[k] = k == n_cand ? g : cg[k];
+                n_cand++;
+                return true;
+            };
+            // While the boundary is only known to lie between two costed offsets more than three steps apart, the next offsets
+            // to cost are chosen where the line through their spare bits crosses zero (and one step - a twelfth of a wide
+            // bracket - either side): the monotone bounds then answer every rung the reference asks about outside the new
+            // bracket.  profiles/search_sim.py replays the policies on the oracle's spare-bit curves: 5.0 -> 3.7 sweeps per cold
+            // frame, 3.0 -> 2.4 per warm one.
+            bool probing = false;
+            if (probe_sweeps < 3 && gl >= 0 && gh > gl + 3) {
+                const int w = gh - gl;
+                const int ge = gl + (int)((float)w * ((float)spare_l / (float)(spare_l - spare_h)) + 0.5f);
+                int d = w > 48 ? (w * 85) >> 10 : 1;
+                d = d < 2 && w > 48 ? 2 : d;
+                auto clampg = [&](int g) { return g < gl + 1 ? gl + 1 : g > gh - 1 ? gh - 1 : g; };
+                add(clampg(ge));
+                add(clampg(ge + d));
+                add(clampg(ge - d));
+                probe_sweeps++;
+                probing = true;
+            }
             // Phase 0 of a search that has to come down a long way (a fresh stream starts at 40): the ladder csnroffst,
             // csnroffst - 4, ... is probed at three points that cut its unknown stretch into quarters instead of walked three
             // rungs per sweep - the bounds above turn a rung that fails or fits by a margin into the verdict of every rung
             // beyond it.  (Which offsets are COSTED never changes a result: the reference's sequence is replayed from exact
             // verdicts only.)
-            if (ss.phase == 0 && (went_down || (first_sweep && cold_hint))) {
+            if (n_cand == 0 && ss.phase == 0 && (went_down || (first_sweep && cold_hint))) {
                 int n = 0;
                 for (int c = ss.csnr; c >= 0 && n < 16; c -= 4, n++) { bool f; if (lookup(c, 0, f)) break; }
                 if (n > 3) {
-                    const int idx[3] = {(n - 1) / 4, (n - 1) / 2, (3 * (n - 1) + 2) / 4};
-                    for (int q = 0; q < 3; q++) {
-                        const int c = ss.csnr - 4 * idx[q];
-                        bool dup = false;
-                        for (int i = 0; i < n_cand; i++) dup = dup || cand_c[i] == c;
-                        if (dup) continue;
-                        const int v = ((c - 15) << 4) << 2;
-                        if (n_cand == 0) for (int k = 0; k < ENC_NC; k++) so[k] = v;
-                        cand_c[n_cand] = c; cand_f[n_cand] = 0;
-                        so[n_cand++] = v;
-                    }
+                    add(16 * (ss.csnr - 4 * ((n - 1) / 4)));
+                    add(16 * (ss.csnr - 4 * ((n - 1) / 2)));
+                    add(16 * (ss.csnr - 4 * ((3 * (n - 1) + 2) / 4)));
                 }
             }
             first_sweep = false;
@@ -1223,19 +1272,13 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                 while (n_cand < ENC_NC && ahead.next(cc, ff)) {
                     bool fits;
                     if (!lookup(cc, ff, fits)) {
-                        bool dup = false;
-                        for (int i = 0; i < n_cand; i++) dup = dup || (cand_c[i] == cc && cand_f[i] == ff);
-                        if (dup) break;
-                        const int v = (((cc - 15) << 4) + ff) << 2;
-                        if (n_cand == 0) for (int q = 0; q < ENC_NC; q++) so[q] = v;
-                        cand_c[n_cand] = cc; cand_f[n_cand] = ff;
-                        so[n_cand++] = v;
+                        if (!add(16 * cc + ff)) break;
                         fits = ahead.phase == 0 ? !went_down : ahead.phase == 1 ? went_up : true;
                     }
                     ahead.consume(fits);
                 }
             }
-            cost_and_record(so, cand_c, cand_f, n_cand);
+            cost_and_record(cg, n_cand, probing);
         }
         if (PART == 3) {
             // Tabulation for the replay (PART 1), whose start value is the previous frame's result, not this pass's:
@@ -1243,16 +1286,17 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
             // answered unless the fit is not monotone around here or the level jumps between frames.
             const int C = ss.failed ? 0 : ss.csnr;
             for (;;) {
-                int so[ENC_NC], cand_c[ENC_NC], cand_f[ENC_NC], n_cand = 0;
+                int cg[ENC_NC], n_cand = 0;
+#pragma unroll
+                for (int k = 0; k < ENC_NC; k++) cg[k] = -1;
                 for (int c = C - 7 < 0 ? 0 : C - 7; c <= (C + 8 > 63 ? 63 : C + 8) && n_cand < ENC_NC; c++) {
                     if ((known_c >> c) & 1) continue;
-                    const int v = ((c - 15) << 4) << 2;
-                    if (n_cand == 0) for (int q = 0; q < ENC_NC; q++) so[q] = v;
-                    cand_c[n_cand] = c; cand_f[n_cand] = 0;
-                    so[n_cand++] = v;
+#pragma unroll
+                    for (int k = 0; k < ENC_NC; k++) cg[k] = k == n_cand ? 16 * c : cg[k];
+                    n_cand++;
                 }
                 if (n_cand == 0) break;
-                cost_and_record(so, cand_c, cand_f, n_cand);
+                cost_and_record(cg, n_cand, false);
             }
             if (lane == 0) {
                 uint32_t *m = P.memo + fidx * 8;

@@ -461,6 +461,11 @@ static int try_offsets(orc_ac3enc_t *s, uint8_t bap[NBLK][MAXCH][256], int frame
     return 16 * s->frame_words - frame_bits;
 }
 
+/* measurement aid (profiles/search_sim.py: how many offsets a search policy has to cost): when set, every search
+   first tabulates the spare bits of its frame at all 1024 offsets g = 16 csnroffst + fsnroffst */
+static int *spare_curve;
+void orc_ac3enc_set_spare_curve(int *dst1024) { spare_curve = dst1024; }
+
 static int search_allocation(orc_ac3enc_t *s, int frame_bits)
 {
     static const int acmod_extra[8] = { 0, 0, 2, 2, 2, 4, 2, 4 };
@@ -496,6 +501,11 @@ static int search_allocation(orc_ac3enc_t *s, int frame_bits)
         for (ch = 0; ch < s->nch_all; ch++)
             compute_mask(s, &p, s->enc_exp[b][ch], s->nb_coefs[ch], ch == s->lfe_ch,
                          s->psd[b][ch], s->mask[b][ch]);
+
+    if (spare_curve) {
+        int g;
+        for (g = 0; g < 1024; g++) spare_curve[g] = try_offsets(s, tmp, frame_bits, p.floor, g >> 4, g & 15);
+    }
 
     /* search order and acceptance exactly as ac3enc.cpp:921-967 */
     csnr = s->csnroffst;

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""How many sweeps (up to NC offsets costed at once) does a candidate policy need to replay the reference's SNR-offset search
+(ENC/ac3enc.cpp:921-967) exactly?  CPU only: the oracle tabulates a frame's spare bits at all 1024 offsets
+(orc_ac3enc_set_spare_curve), the policies below are then run on that curve.  `python profiles/search_sim.py [frames] [start]`.
+Policies mirror enc_pack_kernel's host-free scalar logic (encode.hip): `ladder` = round 3's (quartered ladder + look-ahead),
+`probe` = interpolation probes while the window between the monotone bounds is wide."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import _harness as H
+
+NC = 3
+MARGIN = 72
+
+
+def curves(n, seed=99, second_gen=False):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    S = n
+    t = torch.arange(1536, dtype=torch.float32)
+    ph = torch.rand((S, 1, 6), generator=g) * 6.28
+    fr = 0.01 * torch.arange(1, 7, dtype=torch.float32)
+    pcm = 8000.0 * torch.sin(ph + fr * t[None, :, None]) + (torch.rand((S, 1536, 6), generator=g) - 0.5) * 4096
+    env = torch.where(torch.rand((S, 3, 1, 6), generator=g) < 0.5, 1.0, 1.0 / 32)
+    pcm = (pcm.reshape(S, 3, 512, 6) * env).reshape(S, 1536, 6).round().clamp(-32768, 32767).to(torch.int16).numpy()
+    O = H.orc()
+    O.orc_ac3enc_encode_frames.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, H.i16p, ctypes.c_int, H.u8p, H.u8p]
+    O.orc_ac3enc_set_spare_curve.argtypes = [ctypes.c_void_p]
+    cm = (ctypes.c_uint8 * 8)(*H.CHMAP6)
+    out = []
+    buf = np.zeros(1024, np.int32)
+    O.orc_ac3enc_set_spare_curve(buf.ctypes.data)
+    frame = np.zeros(1536, np.uint8)
+    for i in range(n):
+        src = np.ascontiguousarray(pcm[i].reshape(-1))
+        if second_gen:          # decoded audio fed back: encode, decode to s16, encode that
+            assert O.orc_ac3enc_encode_frames(48000, 384000, 6, H.P(src, H.i16p), 1, cm, H.P(frame, H.u8p)) == 0
+            pcmf, errs, oflags = H.orc_decode(frame[None, :], 7 | 16 | 32, 1.0, 384.0)
+            s16 = np.zeros((6, 256, 6), np.int16)
+            ref16 = np.zeros((256, 6), np.int16)
+            for b in range(6):
+                O.orc_convert_s16(H.P(np.ascontiguousarray(pcmf[0, b]), H.fp), H.P(ref16, H.i16p), oflags)
+                s16[b] = ref16
+            src = np.ascontiguousarray(s16.reshape(-1))
+        assert O.orc_ac3enc_encode_frames(48000, 384000, 6, H.P(src, H.i16p), 1, cm, H.P(frame, H.u8p)) == 0
+        out.append(buf.copy())
+    O.orc_ac3enc_set_spare_curve(None)
+    return out
+
+
+class Search:       # SnrSearch of encode.hip
+    def __init__(self, c):
+        self.c, self.f, self.phase, self.failed = c, 0, 0, False
+
+    def next(self):
+        while True:
+            cc, ff = self.c, self.f
+            if self.phase == 0:
+                if self.c < 0:
+                    self.failed, self.phase = True, 5
+                    return None
+                return cc, ff
+            if self.phase == 1:
+                if self.c + 4 > 63: self.phase = 2; continue
+                return self.c + 4, ff
+            if self.phase == 2:
+                if self.c + 1 > 63: self.phase = 3; continue
+                return self.c + 1, ff
+            if self.phase == 3:
+                if self.f + 4 > 15: self.phase = 4; continue
+                return cc, self.f + 4
+            if self.phase == 4:
+                if self.f + 1 > 15: self.phase = 5; return None
+                return cc, self.f + 1
+            return None
+
+    def consume(self, ok):
+        if self.phase == 0:
+            if ok: self.phase = 1
+            else: self.c -= 4
+        elif self.phase == 1:
+            if ok: self.c += 4
+            else: self.phase = 2
+        elif self.phase == 2:
+            if ok: self.c += 1
+            else: self.phase = 3
+        elif self.phase == 3:
+            if ok: self.f += 4
+            else: self.phase = 4
+        elif self.phase == 4:
+            if ok: self.f += 1
+            else: self.phase = 5
+
+    def copy(self):
+        s = Search(self.c); s.f, s.phase, s.failed = self.f, self.phase, self.failed
+        return s
+
+
+def run(curve, start, policy):
+    """returns (sweeps, (csnr, fsnr))"""
+    known = {}
+    st = {"fit_hi": -1, "fail_lo": 1 << 20, "gl": None, "gh": None}
+    ss = Search(start)
+    sweeps = 0
+    went_down = went_up = False
+    first = True
+    cold = start == 40
+    probes_done = 0
+
+    def lookup(g):
+        if g <= st["fit_hi"]: return True
+        if g >= st["fail_lo"]: return False
+        return known.get(g)
+
+    def cost(gs):
+        nonlocal sweeps
+        sweeps += 1
+        for g in gs:
+            sp = int(curve[g])
+            known[g] = sp >= 0
+            if sp >= MARGIN and g > st["fit_hi"]: st["fit_hi"] = g
+            if sp <= -MARGIN and g < st["fail_lo"]: st["fail_lo"] = g
+            if sp >= 0 and (st["gl"] is None or g > st["gl"][0]): st["gl"] = (g, sp)
+            if sp < 0 and (st["gh"] is None or g < st["gh"][0]): st["gh"] = (g, sp)
+
+    while True:
+        q = None
+        while True:
+            q = ss.next()
+            if q is None: break
+            v = lookup(16 * q[0] + q[1])
+            if v is None: break
+            if ss.phase == 0 and not v: went_down = True
+            if ss.phase == 1 and v: went_up = True
+            ss.consume(v)
+        if q is None: break
+        cand = []
+        if policy == "probe" and probes_done < 3 and st["gl"] is not None and st["gh"] is not None:
+            gl, sl = st["gl"]; gh, sh = st["gh"]
+            lo, hi = max(st["fit_hi"], gl), min(st["fail_lo"], gh)
+            if hi - lo > 3 and gh > gl:
+                est = gl + (gh - gl) * sl / (sl - sh)
+                d = max(1, (gh - gl) // 16)
+                ge = int(round(est))
+                for g in (ge, ge - d, ge + d + 1):
+                    g = min(max(g, lo + 1), hi - 1)
+                    if g not in cand and lookup(g) is None: cand.append(g)
+                probes_done += 1
+        if not cand and ss.phase == 0 and (went_down or (first and cold)):
+            n = 0
+            c = ss.c
+            while c >= 0 and n < 16:
+                if lookup(16 * c) is not None: break
+                c -= 4; n += 1
+            if n > 3:
+                for idx in ((n - 1) // 4, (n - 1) // 2, (3 * (n - 1) + 2) // 4):
+                    g = 16 * (ss.c - 4 * idx)
+                    if g not in cand: cand.append(g)
+        first = False
+        if not cand:
+            ahead = ss.copy()
+            while len(cand) < NC:
+                q2 = ahead.next()
+                if q2 is None: break
+                g = 16 * q2[0] + q2[1]
+                v = lookup(g)
+                if v is None:
+                    if g in cand: break
+                    cand.append(g)
+                    v = (not went_down) if ahead.phase == 0 else went_up if ahead.phase == 1 else True
+                ahead.consume(v)
+        cost(cand[:NC])
+    return sweeps, (ss.c, ss.f)
+
+
+def reference(curve, start):
+    ss = Search(start)
+    while True:
+        q = ss.next()
+        if q is None: break
+        ss.consume(curve[16 * q[0] + q[1]] >= 0)
+    return ss.c, ss.f
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    for name, sg in (("bench PCM", False), ("decoded audio fed back", True)):
+        cs = curves(n, second_gen=sg)
+        for policy in ("ladder", "probe"):
+            for start in ("cold", "warm"):
+                tot = 0
+                for c in cs:
+                    want = reference(c, 40)
+                    s0 = 40 if start == "cold" else want[0]
+                    sw, got = run(c, s0, policy)
+                    assert got == reference(c, s0), (got, reference(c, s0))
+                    tot += sw
+                print("%-24s %-7s %-5s sweeps per frame %.2f" % (name, policy, start, tot / len(cs)))
