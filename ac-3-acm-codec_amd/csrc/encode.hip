@@ -1164,18 +1164,42 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
                     ev = ev1; ev1 = ev2; ev2 = ev3;
                 }
             }
+            // Frame totals.  Plain bits: summed over the blocks in the lane, one reduction per candidate.  The 3/5/11-level counts
+            // of a (block, candidate) pair: three 10-bit fields reduced over either half of the wavefront (32 x 24 < 1024) and
+            // dropped into lane 8 c + B of two collecting registers, so that the ceilings (:1194-1238: a code per 3, 3 or 2
+            // mantissas of a block) are worked out once, across lanes, instead of pair by pair on the scalar unit.
             int total[ENC_NC];
+            {
+                uint32_t col_lo = 0, col_hi = 0, bits_l[ENC_NC];
 #pragma unroll
-            for (int c = 0; c < ENC_NC; c++) total[c] = 0;
+                for (int c = 0; c < ENC_NC; c++) bits_l[c] = 0;
 #pragma unroll
-            for (int B = 0; B < 6; B++) {
+                for (int B = 0; B < 6; B++) {
 #pragma unroll
-                for (int c = 0; c < ENC_NC; c++) {
-                    const uint32_t sa = wave_sum_u32((acc[B][c] & 0x1ffu) | (((acc[B][c] >> 9) & 31u) << 16));
-                    const uint32_t sb = wave_sum_u32(((acc[B][c] >> 14) & 31u) | (((acc[B][c] >> 19) & 31u) << 16));
-                    const int bits = sa & 0xffff, n1 = sa >> 16, n2 = sb & 0xffff, n4 = sb >> 16;
-                    total[c] += bits + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+                    for (int c = 0; c < ENC_NC; c++) {
+                        const uint32_t a = acc[B][c];
+                        bits_l[c] += a & 0x1ffu;
+                        uint32_t v = ((a >> 9) & 31u) | (((a >> 14) & 31u) << 10) | (((a >> 19) & 31u) << 20);
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+                        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+                        const bool mine = lane == 8 * c + B;
+                        col_lo = mine ? lo : col_lo;
+                        col_hi = mine ? hi : col_hi;
+                    }
                 }
+                const uint32_t n1 = (col_lo & 1023u) + (col_hi & 1023u), n2 = ((col_lo >> 10) & 1023u) + ((col_hi >> 10) & 1023u);
+                const uint32_t n4 = (col_lo >> 20) + (col_hi >> 20);
+                uint32_t t = 5u * (((n1 + 2u) * 0xaaabu) >> 17) + 7u * (((n2 + 2u) * 0xaaabu) >> 17) + 7u * ((n4 + 1u) >> 1);
+                t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xf, 0xf, true);      // lanes 8 c .. 8 c + 7 -> lane 8 c + 7
+                t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xf, 0xf, true);
+                t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, true);
+#pragma unroll
+                for (int c = 0; c < ENC_NC; c++)
+                    total[c] = (int)wave_sum_u32(bits_l[c]) + __builtin_amdgcn_readlane((int)t, 8 * c + 7);
             }
 #pragma unroll
             for (int i = 0; i < ENC_NC; i++) {
