@@ -63,8 +63,10 @@ struct PackParams {
     int nch, nfbw, lfe, acmod, fscod, halfrate, bsid, frmsizecod, frame_words;
     int nbc;                    // coefficients per full-bandwidth channel (223)
     int chbwcod;
-    uint32_t crc_inv;           // x^-(16*fs58-16) mod poly (:1627)
-    uint32_t pw1[6], pw2[6];    // x^(8*C*2^k) mod poly for the two CRC regions
+    // CRC constants as multiplication tables: entry i = constant * x^i mod poly, so that a product with a per-lane value is 16
+    // select-and-xor steps with no scalar chain (gf_mul_tab)
+    uint16_t crc_inv_t[16];     // x^-(16*fs58-16) mod poly (:1627)
+    uint16_t pw1_t[6][16], pw2_t[6][16];    // x^(8*C*2^k) mod poly for the two CRC regions
     int c1, c2;                 // CRC chunk bytes per lane
     int frw;                    // dwords of the frame buffer in (dynamic) LDS: the frame + 256 bytes of headroom, multiple of 4
     int marker;                 // the reference's "member already merged" value, 128 (:1375-1413); AC3MI_ENC_MARKER: test aid
@@ -888,8 +890,17 @@ __device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :116
 
 // CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
 // bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
+// a * t[0] in GF(2)[x]/poly for a table t[i] = t[0] * x^i mod poly (wave-uniform, from the kernel arguments)
+__device__ __forceinline__ uint32_t gf_mul_tab(uint32_t a, const uint16_t *t)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c ^= (uint32_t)__builtin_amdgcn_sbfe((int)a, i, 1) & (uint32_t)t[i];
+    return c;
+}
+
 template <class LDS>
-__device__ uint32_t region_crc(const LDS &L, const uint32_t *fr, int end, int len, int C, const uint32_t *pw, int zero_below, int lane)
+__device__ uint32_t region_crc(const LDS &L, const uint32_t *fr, int end, int len, int C, const uint16_t (*pw)[16], int zero_below, int lane)
 {
     const int start = end - 64 * C;                 // may be negative: leading zero padding
     int p = start + lane * C;
@@ -903,7 +914,7 @@ __device__ uint32_t region_crc(const LDS &L, const uint32_t *fr, int end, int le
     for (int k = 0; k < 6; k++) {
         const int d = 1 << k;
         const uint32_t left = __shfl_up(crc, d, 64);
-        if (((lane + 1) & (2 * d - 1)) == 0) crc = gf_mul(left, pw[k]) ^ crc;
+        if (((lane + 1) & (2 * d - 1)) == 0) crc = gf_mul_tab(left, pw[k]) ^ crc;
     }
     return __shfl(crc, 63, 64);
 }
@@ -941,8 +952,11 @@ __device__ unsigned long long g_pack_cycles[8];
 #ifndef ENC_PACK_LB
 #define ENC_PACK_LB 4            // wavefronts per SIMD the packer's register budget is set for (128 VGPRs; at 5 the branch-free mantissa passes spill: 6.26 vs 6.09 ms per 65 536 frames)
 #endif
+#ifndef ENC_SEARCH_LB
+#define ENC_SEARCH_LB ENC_PACK_LB
+#endif
 template <int PART>
-__global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
 {
     __shared__ PackLDS L;
     extern __shared__ uint4 pk_dyn[];
@@ -1642,9 +1656,9 @@ __global__ __launch_bounds__(64, ENC_PACK_LB) void enc_pack_kernel(const PackPar
         const int fs58 = (fs >> 1) + (fs >> 3);
         // clear everything from byte 2*fs-2 on? no: the reference only zero-pads when the data is short;
         // data bits beyond byte 2*fs-2 stay and are then overwritten by crc2 (its own overshoot quirk)
-        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
-        crc1 = gf_mul(P.crc_inv, crc1);
-        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
+        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1_t, 4, lane);
+        crc1 = gf_mul_tab(crc1, P.crc_inv_t);
+        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2_t, 0, lane);
         WAVE_SYNC();
         if (lane == 0) {
             fr[0] = (fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
@@ -2052,11 +2066,11 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
     // ---- frame end (:1599-1638): the two CRC regions on two wavefronts, then the frame goes out ----
     const int fs58 = (fs >> 1) + (fs >> 3);
     if (b == 0) {
-        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1, 4, lane);
-        crc1 = gf_mul(P.crc_inv, crc1);
+        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1_t, 4, lane);
+        crc1 = gf_mul_tab(crc1, P.crc_inv_t);
         if (lane == 0) L.crc[0] = crc1;
     } else if (b == 1) {
-        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2, 0, lane);
+        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2_t, 0, lane);
         if (lane == 0) L.crc[1] = crc2;
     }
     __syncthreads();
@@ -2170,13 +2184,16 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.nbc = 223;
     P.chbwcod = 50;
     const int fs = c.frame_words, fs58 = (fs >> 1) + (fs >> 3);
-    P.crc_inv = h_gf_pow(0x18005 >> 1, 16 * fs58 - 16);
+    auto times_x = [](uint16_t *t, uint32_t v) {                    // t[i] = v * x^i mod poly
+        for (int i = 0; i < 16; i++) { t[i] = (uint16_t)v; v = h_gf_mul(v, 2); }
+    };
+    times_x(P.crc_inv_t, h_gf_pow(0x18005 >> 1, 16 * fs58 - 16));
     const int len1 = 2 * fs58, len2 = (fs - fs58) * 2 - 2;
     P.c1 = (len1 + 63) / 64;
     P.c2 = (len2 + 63) / 64;
     for (int k = 0; k < 6; k++) {
-        P.pw1[k] = h_gf_pow(2, 8u * P.c1 * (1u << k));
-        P.pw2[k] = h_gf_pow(2, 8u * P.c2 * (1u << k));
+        times_x(P.pw1_t[k], h_gf_pow(2, 8u * P.c1 * (1u << k)));
+        times_x(P.pw2_t[k], h_gf_pow(2, 8u * P.c2 * (1u << k)));
     }
     P.snr = E.ws_snr;
     P.memo = nullptr;
