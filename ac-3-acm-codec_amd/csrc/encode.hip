@@ -484,49 +484,45 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
             if (lane < nsingle) L.mask[r][lane] = (int16_t)(3072 - ((int)(int8_t)L.E[r][lane] << 7));
         }
         if (n > 28) {
-            for (uint32_t m = starts; m;) {
-                const int ra = __builtin_ctz(m);
-                m &= m - 1;
-                const bool two = m != 0;
-                const int rb = two ? __builtin_ctz(m) : ra;
-                m &= m - 1;
-                const int half = lane >> 5, band = 28 + (lane & 31);
-                const int r = half ? rb : ra;
-                const bool active = (lane & 31) < 22 && (half == 0 || two);
-                const int start = L.t.band_start[active ? band : 28];
-                int end1 = L.t.band_start[active ? band + 1 : 29];
-                end1 = end1 < n ? end1 : n;
-                const int wdt = active ? end1 - start : 0;
-                // the band's exponents: seven dwords of the row, shifted so that byte 0 is its first bin; the sweep's only
-                // dependent LDS access per step is then the log-add table (as in the decoder's bit allocation, decode_common.h)
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(&L.E[r][start & ~3]);
-                uint32_t dw[7], ab[6];
+            // Ten lanes per row, six rows in ONE sweep of 23 steps: a lane integrates a stretch of equally wide bands one after
+            // the other (bands 28..49 start at 28 31 .. 46 | 49 55 .. 79 | 85 97 109 121 | 133 157 181 205 229): slots 0-4 a
+            // 24-bin band each, 5-6 two 12-bin bands, 7 four and 8 two 6-bin bands, 9 the seven 3-bin bands - at most 24 bins.
+            const int r = (lane * 205) >> 11, slot = lane - 10 * r;                 // lane / 10, lane % 10
+            const int fb = slot < 5 ? 45 + slot : slot == 5 ? 41 : slot == 6 ? 43 : slot == 7 ? 35 : slot == 8 ? 39 : 28;
+            const int nb = slot < 5 ? 1 : slot < 7 ? 2 : slot == 7 ? 4 : slot == 8 ? 2 : 7;
+            const int lw = slot < 5 ? 3 : slot < 7 ? 2 : slot < 9 ? 1 : 0;          // bands of 3 << lw bins
+            const bool rowon = lane < 60 && ((starts >> r) & 1u);
+            const int rr = rowon ? r : 0;
+            const int start = L.t.band_start[fb];
+            int end1 = L.t.band_start[fb + nb];
+            end1 = end1 < n ? end1 : n;
+            const int len = rowon ? end1 - start : 0;                               // bins of the stretch inside the channel
+            // the stretch's exponents: seven dwords of the row, shifted so that byte 0 is its first bin; the sweep's only
+            // dependent LDS access per step is then the log-add table (as in the decoder's bit allocation, decode_common.h)
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(&L.E[rr][start & ~3]);
+            uint32_t dw[7], ab[6];
 #pragma unroll
-                for (int i = 0; i < 7; i++) dw[i] = q[i];
+            for (int i = 0; i < 7; i++) dw[i] = q[i];
 #pragma unroll
-                for (int i = 0; i < 6; i++) ab[i] = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], (uint32_t)start & 3u);
-                int v = 3072 - ((int)(ab[0] & 0xffu) << 7);
-                auto step = [&](int j) __attribute__((always_inline)) {
-                    const int pj = 3072 - ((int)((ab[j >> 2] >> (8 * (j & 3))) & 0xffu) << 7);
-                    const int c = v - pj;
-                    int t = (c >= 0 ? c : -c) >> 1;
-                    t = t > 255 ? 255 : t;
-                    const int nv = (c >= 0 ? v : pj) + (int)L.t.latab[t];
-                    v = j < wdt ? nv : v;
-                };
-                // bands are 3, 6, 12 or 24 bins wide (fewer at the channel's edge)
-                if (__any(wdt > 1)) { step(1); step(2); }
-                if (__any(wdt > 3)) { step(3); step(4); step(5); }
-                if (__any(wdt > 6)) {
+            for (int i = 0; i < 6; i++) ab[i] = __builtin_amdgcn_alignbyte(dw[i + 1], dw[i], (uint32_t)start & 3u);
+            int16_t *mrow = &L.mask[rr][fb];
+            const bool r3 = lw == 0, r6 = lw <= 1, r12 = lw <= 2;
+            int v = 3072 - ((int)(ab[0] & 0xffu) << 7);
 #pragma unroll
-                    for (int j = 6; j < 12; j++) step(j);
+            for (int j = 1; j < 24; j++) {
+                const int pj = 3072 - ((int)((ab[j >> 2] >> (8 * (j & 3))) & 0xffu) << 7);
+                const int c = v - pj;
+                int t = (c >= 0 ? c : -c) >> 1;
+                t = t > 255 ? 255 : t;
+                int nv = (c >= 0 ? v : pj) + (int)L.t.latab[t];
+                if (j % 3 == 0) {                                                   // a band may end here
+                    const bool ends = j % 12 == 0 ? r12 : j % 6 == 0 ? r6 : r3;
+                    if (ends && j < len) mrow[((j / 3) >> lw) - 1] = (int16_t)v;
+                    nv = ends ? pj : nv;
                 }
-                if (__any(wdt > 12)) {
-#pragma unroll
-                    for (int j = 12; j < 24; j++) step(j);
-                }
-                if (wdt > 0) L.mask[r][band] = (int16_t)v;
+                v = j < len ? nv : v;
             }
+            if (len > 0) mrow[((((uint32_t)(len - 1)) * 0xaaabu) >> 17) >> lw] = (int16_t)v;
         }
         WAVE_SYNC();
         // fixed allocation codes (:861-879)
