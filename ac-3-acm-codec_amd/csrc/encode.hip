@@ -83,7 +83,7 @@ struct MaskTabs {
 };
 
 struct alignas(16) PackLDS {
-    int16_t mask[36][50];       // masking curve per (blk, ch), minus the floor
+    int16_t mask[36][50];       // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
     uint32_t gtab[640];         // 3/5/11-level codes being assembled, rings of 128 / 128 / 256: bit offset | 16-bit code << 16; from 512 on two
                                 // sink words per lane: where stores, adds and put_bits_always of lanes with nothing to say go
     uint32_t bitlut[64];        // see lut_index
@@ -1012,8 +1012,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
 #pragma unroll
                 for (int j = 0; j < 15; j++) {
                     const int i = lane + 64 * j;
-                    const int row = i / 25, w = i - 25 * row, b = row / nch, ch = row - b * nch;
-                    if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[b * 6 + ch][0])[w] = mv[j];
+                    if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[0][0])[i] = mv[j];
                 }
                 if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             }
@@ -1040,7 +1039,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                     const uint32_t later = (uint32_t)((run_starts >> (8 * c6)) & 0x3f) | 0x40u;       // bit b: block b of this channel sends exponents
                     const int b1 = __builtin_ctz(later >> (b6 + 1)) + b6 + 1;
                     const uint32_t cover = ((1u << b1) - 1u) & ~((1u << b6) - 1u);
-                    const uint32_t d = (uint32_t)((b6 * nch + c6) * 256) | ((P.lfe && c6 == nch - 1) ? 1u << 14 : 0u) | (cover << 16) | ((uint32_t)lane << 24);
+                    const uint32_t d = (uint32_t)((b6 * nch + c6) * 256) | ((P.lfe && c6 == nch - 1) ? 1u << 14 : 0u) | (cover << 16) | ((uint32_t)(b6 * nch + c6) << 24);
                     L.rowdesc[__builtin_popcountll(row_set & ((1ull << lane) - 1ull))] = d;
                 }
             }
@@ -1498,7 +1497,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                     }
                     const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
                     const bool lfe_lane = merged && lk >= 0;
-                    const int16_t *Mr = &L.mask[b * 6 + ch][0];
+                    const int16_t *Mr = &L.mask[b * nch + ch][0];
                     int shv = (int)L.shiftv[b * 6 + ch];
                     uint32_t bands = bandoff;
                     if (merged) {
@@ -1508,7 +1507,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         const uint32_t lexp = ((uint32_t)__shfl((int)le, lk >= 0 ? lk >> 2 : 0, 64) >> (8 * (lk & 3))) & 0xffu;
                         e4 = lfe_lane ? lexp : e4;
                         c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
-                        Mr = lfe_lane ? &L.mask[b * 6 + nch - 1][0] : Mr;
+                        Mr = lfe_lane ? &L.mask[b * nch + nch - 1][0] : Mr;
                         shv = lfe_lane ? (int)L.shiftv[b * 6 + nch - 1] : shv;
                         bands = lfe_lane ? (uint32_t)lk : bands;              // (LFE bins 0..6 are bands 0..6)
                     }
@@ -1734,10 +1733,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
     const size_t rowb = (fidx * 6 + b) * nch;
     {
         const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + rowb * 50);
-        for (int i = lane; i < nch * 25; i += 64) {
-            const int row = i / 25, w = i - 25 * row;
-            reinterpret_cast<uint32_t *>(&W.mask[row][0])[w] = gm[i];
-        }
+        for (int i = lane; i < nch * 25; i += 64) reinterpret_cast<uint32_t *>(&W.mask[0][0])[i] = gm[i];
     }
     // lane = channel: exponent strategy and exp_samples of the block's channels
     const int strat_l = lane < nch ? (int)P.strat[rowb + lane] : 0;
