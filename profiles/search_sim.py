@@ -141,14 +141,13 @@ def run(curve, start, policy):
         cand = []
         if policy == "probe" and probes_done < 3 and st["gl"] is not None and st["gh"] is not None:
             gl, sl = st["gl"]; gh, sh = st["gh"]
-            lo, hi = max(st["fit_hi"], gl), min(st["fail_lo"], gh)
-            if hi - lo > 3 and gh > gl:
-                est = gl + (gh - gl) * sl / (sl - sh)
-                d = max(1, (gh - gl) // 16)
-                ge = int(round(est))
-                for g in (ge, ge - d, ge + d + 1):
-                    g = min(max(g, lo + 1), hi - 1)
-                    if g not in cand and lookup(g) is None: cand.append(g)
+            if gh > gl + 3:                     # as encode.hip: the line through the two nearest costed points, +- a step
+                w = gh - gl
+                ge = gl + int(w * (sl / (sl - sh)) + 0.5)
+                d = max(2, (w * 85) >> 10) if w > 48 else 1
+                for g in (ge, ge + d, ge - d):
+                    g = min(max(g, gl + 1), gh - 1)
+                    if g not in cand: cand.append(g)
                 probes_done += 1
         if not cand and ss.phase == 0 and (went_down or (first and cold)):
             n = 0
