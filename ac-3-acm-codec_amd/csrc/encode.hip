@@ -1290,6 +1290,12 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
             // rungs per sweep - the bounds above turn a rung that fails or fits by a margin into the verdict of every rung
             // beyond it.  (Which offsets are COSTED never changes a result: the reference's sequence is replayed from exact
             // verdicts only.)
+            if (n_cand == 0 && first_sweep && cold_hint) {
+                // a fresh stream's first sweep: csnroffst 8, 13 and 20, around where material lands at the usual rates (64 kbps
+                // mono to 640 kbps 5.1: boundary at 8 .. 16 1/2 in profiles/search_sim.py) - 3.8 -> 3.5 sweeps per cold frame
+                // against quartering 0 .. 40, no worse at the extremes
+                add(16 * 8); add(16 * 13); add(16 * 20);
+            }
             if (n_cand == 0 && ss.phase == 0 && (went_down || (first_sweep && cold_hint))) {
                 int n = 0;
                 for (int c = ss.csnr; c >= 0 && n < 16; c -= 4, n++) { bool f; if (lookup(c, 0, f)) break; }

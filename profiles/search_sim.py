@@ -149,6 +149,8 @@ def run(curve, start, policy):
                     g = min(max(g, gl + 1), gh - 1)
                     if g not in cand: cand.append(g)
                 probes_done += 1
+        if policy == "probe" and not cand and first and cold:
+            cand = [16 * 8, 16 * 13, 16 * 20]
         if not cand and ss.phase == 0 and (went_down or (first and cold)):
             n = 0
             c = ss.c
