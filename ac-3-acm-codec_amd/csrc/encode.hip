@@ -604,6 +604,7 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
     {
         const unsigned n = gridDim.x, q = n >> 3, r = n & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
         unit = (int)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i);
+        unit = __builtin_amdgcn_readfirstlane(unit);        // (wave-uniform by construction: row and state addresses on the scalar unit)
     }
     const int ch = unit % P.nch;
     const int sf = unit / P.nch;
@@ -647,12 +648,15 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
     // the lane's four samples of: the block before (history), this block, and - in flight while this block is
     // transformed - the next one.  Every sample is read from HBM once.
     int16_t oldv[4], newv[4], nxtv[4];
+    int joff[4];                                    // the lane's positions as sample offsets (32-bit index arithmetic)
+#pragma unroll
+    for (int k = 0; k < 4; k++) joff[k] = __mul24(jpos[k], P.nch);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = jpos[k];
-        if (f > 0) oldv[k] = frame_pcm[-(ptrdiff_t)((256 - j) * P.nch)];         // block 5 of the previous frame
+        if (f > 0) oldv[k] = frame_pcm[joff[k] - 256 * P.nch];                   // block 5 of the previous frame
         else oldv[k] = P.slot ? P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] : P.last[((size_t)s * P.nch + ch) * 256 + j];
-        newv[k] = frame_pcm[(size_t)j * P.nch];
+        newv[k] = frame_pcm[joff[k]];
     }
     for (int blk = 0; blk < 6; blk++) {
         // ---- 512 input samples: 256 old + 256 new (:1673-1683), windowed (:1686-1693) - in registers ----
@@ -660,13 +664,13 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = jpos[k];
-            nxtv[k] = blk < 5 ? frame_pcm[(size_t)((blk + 1) * 256 + j) * P.nch] : (int16_t)0;
+            nxtv[k] = blk < 5 ? frame_pcm[(blk + 1) * 256 * P.nch + joff[k]] : (int16_t)0;
             if (P.store_history && blk == 5) {
                 if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
                 else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
             }
-            win_[k] = (int16_t)((oldv[k] * wa[k]) >> 15);
-            win_[4 + k] = (int16_t)((newv[k] * wb[k]) >> 15);
+            win_[k] = (int16_t)(__mul24(oldv[k], wa[k]) >> 15);
+            win_[4 + k] = (int16_t)(__mul24(newv[k], wb[k]) >> 15);
             oldv[k] = newv[k];
         }
         // ---- block floating point (:1697-1700) ----
@@ -685,10 +689,11 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
         {
             const int re0 = ((int)(int16_t)(-N[2]) - N[1]) >> 1, im0 = (-(O[2] - O[1])) >> 1;
             const int re1 = (O[0] - O[3]) >> 1, im1 = (-(N[0] - (int)(int16_t)(-N[3]))) >> 1;
-            pr = (int16_t)((re0 * pcv[0] - im0 * psv[0]) >> 15);
-            pi = (int16_t)((re0 * psv[0] + pcv[0] * im0) >> 15);
-            qr = (int16_t)((re1 * pcv[1] - im1 * psv[1]) >> 15);
-            qi = (int16_t)((re1 * psv[1] + pcv[1] * im1) >> 15);
+            // (every product of this kernel has operands of 17 bits at most: the 24-bit multiplier, not the quarter-rate 32-bit one)
+            pr = (int16_t)((__mul24(re0, pcv[0]) - __mul24(im0, psv[0])) >> 15);
+            pi = (int16_t)((__mul24(re0, psv[0]) + __mul24(pcv[0], im0)) >> 15);
+            qr = (int16_t)((__mul24(re1, pcv[1]) - __mul24(im1, psv[1])) >> 15);
+            qi = (int16_t)((__mul24(re1, psv[1]) + __mul24(pcv[1], im1)) >> 15);
         }
         // ---- the seven passes (:508-567) in registers: the lane's butterfly of pass k takes the points ip = (lane / d) 2d +
         //      lane mod d and ip + d (d = 2^k); between two passes every lane trades ONE point with lane ^ d (the upper half of
@@ -716,8 +721,8 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
         for (int k = 0; k < 5; k++) {                                       // passes 2..6
             const int nloops = 4 << k;
             const int c = twc[k], sx = tws[k];
-            const int tr = (c * qr - sx * qi) >> 15;
-            const int ti = (c * qi + qr * sx) >> 15;
+            const int tr = (__mul24(c, qr) - __mul24(sx, qi)) >> 15;
+            const int ti = (__mul24(c, qi) + __mul24(qr, sx)) >> 15;
             const bool plain = (lane & (nloops - 1)) == 0;
             bfly_r(plain ? qr : tr, plain ? qi : ti);
             if (k < 4) trade(nloops);
@@ -725,10 +730,10 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
         // ---- post-rotation (:596-602): the lane now holds points lane and lane + 64 ----
         {
             const int sx0 = xsv[0], c0 = xcv[0], sx1 = xsv[1], c1 = xcv[1];
-            out[2 * lane] = (pr * c0 + sx0 * pi) >> 15;
-            out[255 - 2 * lane] = (pr * sx0 - pi * c0) >> 15;
-            out[2 * (lane + 64)] = (qr * c1 + sx1 * qi) >> 15;
-            out[255 - 2 * (lane + 64)] = (qr * sx1 - qi * c1) >> 15;
+            out[2 * lane] = (__mul24(pr, c0) + __mul24(sx0, pi)) >> 15;
+            out[255 - 2 * lane] = (__mul24(pr, sx0) - __mul24(pi, c0)) >> 15;
+            out[2 * (lane + 64)] = (__mul24(qr, c1) + __mul24(sx1, qi)) >> 15;
+            out[255 - 2 * (lane + 64)] = (__mul24(qr, sx1) - __mul24(qi, c1)) >> 15;
         }
         WAVE_SYNC();
         // ---- exponents (:1707-1722) ----
@@ -1566,7 +1571,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         const int q = ((pw[j] >> 14) & 1u) ? vs : va;
                         const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
                         vq[j] = (uint32_t)q & 0xffffu;
-                        vw[j] = (uint32_t)(q * wgt) << 16;
+                        vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;     // (only the product's low 16 bits count: a 24-bit multiply, not the quarter-rate 32-bit one)
                     }
                     if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
 #pragma unroll
@@ -1980,7 +1985,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
                     const int q = ((pw[j] >> 14) & 1u) ? vs : va;
                     const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
                     vq[j] = (uint32_t)q & 0xffffu;
-                    vw[j] = (uint32_t)(q * wgt) << 16;
+                    vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;
                 }
                 if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
 #pragma unroll
