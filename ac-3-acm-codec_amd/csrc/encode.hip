@@ -706,27 +706,60 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
             qr = (int16_t)((bx - ax) >> 1);
             qi = (int16_t)((by - ay) >> 1);
         };
-        auto trade = [&](int d) {
-            const bool up = (lane & d) != 0;
-            const int sr = up ? pr : qr, si = up ? pi : qi;
-            const int rr = __shfl_xor(sr, d, 64), ri = __shfl_xor(si, d, 64);
-            pr = up ? rr : pr; pi = up ? ri : pi;
-            qr = up ? qr : rr; qi = up ? qi : ri;
+        // lane ^ d without LDS: quad permutes (d = 1, 2), row shifts by bank (4), a row rotation (8); for d = 16 and 32 the trade
+        // IS gfx950's v_permlane16_swap / v_permlane32_swap of (p, q): odd rows / the upper half of p against even rows / the
+        // lower half of q
+        auto trade = [&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d == 32) {
+                const auto r = __builtin_amdgcn_permlane32_swap((unsigned)pr, (unsigned)qr, false, false);
+                const auto i = __builtin_amdgcn_permlane32_swap((unsigned)pi, (unsigned)qi, false, false);
+                pr = (int)r[0]; qr = (int)r[1]; pi = (int)i[0]; qi = (int)i[1];
+            } else if constexpr (d == 16) {
+                const auto r = __builtin_amdgcn_permlane16_swap((unsigned)pr, (unsigned)qr, false, false);
+                const auto i = __builtin_amdgcn_permlane16_swap((unsigned)pi, (unsigned)qi, false, false);
+                pr = (int)r[0]; qr = (int)r[1]; pi = (int)i[0]; qi = (int)i[1];
+            } else {
+                const bool up = (lane & d) != 0;
+                const int sr = up ? pr : qr, si = up ? pi : qi;
+                int rr, ri;
+                if constexpr (d == 1) {
+                    rr = __builtin_amdgcn_update_dpp(0, sr, 0xb1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
+                    ri = __builtin_amdgcn_update_dpp(0, si, 0xb1, 0xf, 0xf, false);
+                } else if constexpr (d == 2) {
+                    rr = __builtin_amdgcn_update_dpp(0, sr, 0x4e, 0xf, 0xf, false);         // quad_perm [2,3,0,1]
+                    ri = __builtin_amdgcn_update_dpp(0, si, 0x4e, 0xf, 0xf, false);
+                } else if constexpr (d == 4) {
+                    rr = __builtin_amdgcn_update_dpp(0, sr, 0x104, 0xf, 0x5, false);        // row_shl:4 into banks 0, 2
+                    rr = __builtin_amdgcn_update_dpp(rr, sr, 0x114, 0xf, 0xa, false);       // row_shr:4 into banks 1, 3
+                    ri = __builtin_amdgcn_update_dpp(0, si, 0x104, 0xf, 0x5, false);
+                    ri = __builtin_amdgcn_update_dpp(ri, si, 0x114, 0xf, 0xa, false);
+                } else {
+                    static_assert(d == 8, "");
+                    rr = __builtin_amdgcn_update_dpp(0, sr, 0x128, 0xf, 0xf, false);        // row_ror:8
+                    ri = __builtin_amdgcn_update_dpp(0, si, 0x128, 0xf, 0xf, false);
+                }
+                pr = up ? rr : pr; pi = up ? ri : pi;
+                qr = up ? qr : rr; qi = up ? qi : ri;
+            }
         };
         bfly_r(qr, qi);                                                     // pass 0
-        trade(1);
+        trade(std::integral_constant<int, 1>{});
         if (lane & 1) bfly_r(qi, -qr); else bfly_r(qr, qi);                 // pass 1: twiddles 1 and -j
-        trade(2);
-#pragma unroll
-        for (int k = 0; k < 5; k++) {                                       // passes 2..6
+        trade(std::integral_constant<int, 2>{});
+        auto pass = [&](int k) {                                            // passes 2..6
             const int nloops = 4 << k;
             const int c = twc[k], sx = tws[k];
             const int tr = (__mul24(c, qr) - __mul24(sx, qi)) >> 15;
             const int ti = (__mul24(c, qi) + __mul24(qr, sx)) >> 15;
             const bool plain = (lane & (nloops - 1)) == 0;
             bfly_r(plain ? qr : tr, plain ? qi : ti);
-            if (k < 4) trade(nloops);
-        }
+        };
+        pass(0); trade(std::integral_constant<int, 4>{});
+        pass(1); trade(std::integral_constant<int, 8>{});
+        pass(2); trade(std::integral_constant<int, 16>{});
+        pass(3); trade(std::integral_constant<int, 32>{});
+        pass(4);
         // ---- post-rotation (:596-602): the lane now holds points lane and lane + 64 ----
         {
             const int sx0 = xsv[0], c0 = xcv[0], sx1 = xsv[1], c1 = xcv[1];
