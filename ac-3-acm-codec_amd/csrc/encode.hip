@@ -588,7 +588,7 @@ __device__ __forceinline__ void bfly(c16 &p, c16 &q, int bx, int by, int ax, int
 }
 
 #ifndef ENC_MDCT_LB
-#define ENC_MDCT_LB 5        // 96 VGPRs, no scratch: 6.60 against 6.73 ms per 65 536 cold frames at 6 (80 VGPRs, 28 bytes of scratch)
+#define ENC_MDCT_LB 7        // 71 VGPRs, no scratch: 1.97 ms against 2.00 at 5 or 6 (75 VGPRs) and 2.07 at 8 (64 VGPRs, 24 bytes of scratch)
 #endif
 __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctParams P)
 {
