@@ -1413,31 +1413,28 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
         PK_LAP(0);
         // ---- header (:1113-1147) ----
         // Side information is wave-uniform: its fields collect in a 64-bit accumulator that stays in scalar registers and
-        // reach the LDS frame 32 bits at a time (one lane, one put_bits per word instead of one per field); `flush` empties
-        // it before the lanes write at `pos` themselves (exponent groups, mantissas).
+        // reach the LDS frame up to 64 bits at a time (one lane, two put_bits): `flush` empties it before the lanes write at
+        // `pos` themselves (exponent groups, mantissas) and wherever the next stretch of fields could overflow it - the block's
+        // first stretch is 54 bits at most, the one after the exponents 63 (block 0 of six channels).
         uint32_t pos = 0;                   // first bit not yet in the frame
         uint64_t acc = 0;
         int nacc = 0;                       // pending bits, the low `nacc` of acc
-        auto put = [&](int n, uint32_t v) {
-            acc = (acc << n) | v;
-            nacc += n;
-            if (nacc >= 32) {
-                const uint32_t word = (uint32_t)(acc >> (nacc - 32));
-                if (lane == 0) put_bits(fr, P.frw, pos, 32, word);
-                pos += 32;
-                nacc -= 32;
-            }
-        };
+        auto put = [&](int n, uint32_t v) { acc = (acc << n) | v; nacc += n; };       // (no test per field: at most 64 bits between two flushes)
         auto flush = [&]() {
+            if (nacc > 32) {
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc - 32, (uint32_t)(acc >> 32) & (0xffffffffu >> (64 - nacc)));
+                pos += nacc - 32;
+                nacc = 32;
+            }
             if (nacc > 0) {
-                const uint32_t word = (uint32_t)acc & (0xffffffffu >> (32 - nacc));
-                if (lane == 0) put_bits(fr, P.frw, pos, nacc, word);
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc, (uint32_t)acc & (0xffffffffu >> (32 - nacc)));
                 pos += nacc;
                 nacc = 0;
             }
         };
         auto uni = [&](int v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); };
         put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+        flush();
         if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
         if (P.acmod & 4) put(2, 1);
         if (P.acmod == 2) put(2, 0);
@@ -1450,6 +1447,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
             uint32_t ew[6];
 #pragma unroll
             for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane) : 0u;
+            flush();
             for (int ch = 0; ch < nfbw; ch++) put(1, 0);
             for (int ch = 0; ch < nfbw; ch++) put(1, 1);
             put(1, 0);
@@ -1485,6 +1483,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                 pos += 7 * ng;
                 if (!is_lfe) put(2, 0);
             }
+            if (b == 0) flush();
             put(1, b == 0);
             if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
             put(1, b == 0);
@@ -1861,20 +1860,15 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         // ---- side information (wave-uniform fields through a 64-bit accumulator, see enc_pack_kernel) ----
         uint64_t acc = 0;
         int nacc = 0;
-        auto put = [&](int n, uint32_t v) {
-            acc = (acc << n) | v;
-            nacc += n;
-            if (nacc >= 32) {
-                const uint32_t word = (uint32_t)(acc >> (nacc - 32));
-                if (lane == 0) put_bits(fr, P.frw, pos, 32, word);
-                pos += 32;
-                nacc -= 32;
-            }
-        };
+        auto put = [&](int n, uint32_t v) { acc = (acc << n) | v; nacc += n; };       // (no test per field: at most 64 bits between two flushes)
         auto flush = [&]() {
+            if (nacc > 32) {
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc - 32, (uint32_t)(acc >> 32) & (0xffffffffu >> (64 - nacc)));
+                pos += nacc - 32;
+                nacc = 32;
+            }
             if (nacc > 0) {
-                const uint32_t word = (uint32_t)acc & (0xffffffffu >> (32 - nacc));
-                if (lane == 0) put_bits(fr, P.frw, pos, nacc, word);
+                if (lane == 0) put_bits(fr, P.frw, pos, nacc, (uint32_t)acc & (0xffffffffu >> (32 - nacc)));
                 pos += nacc;
                 nacc = 0;
             }
@@ -1883,6 +1877,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
             const uint32_t mine = pos;
             pos = 0;
             put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+            flush();
             if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
             if (P.acmod & 4) put(2, 1);
             if (P.acmod == 2) put(2, 0);
@@ -1925,6 +1920,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
             pos += 7 * ng;
             if (!is_lfe) put(2, 0);
         }
+        if (b == 0) flush();
         put(1, b == 0);
         if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
         put(1, b == 0);
