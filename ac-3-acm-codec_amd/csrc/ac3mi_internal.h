@@ -137,6 +137,7 @@ struct EncodeLaunch {
     int frame_stride, n_streams, frames_per_stream;
     uint8_t chmap[8];
     int32_t *ws_mdct;           // [S][F][6][nch][256]
+    bool mdct_full_rows = false; // the rows are a stage tap: all 256 bins are stored, not only the coded ones
     uint8_t *ws_expo;           // [S][F][6][nch][256]
     int8_t *ws_shift;           // [S][F][6][nch]
     uint8_t *ws_eexp;           // [S][F][6][nch][256] encoded exponents

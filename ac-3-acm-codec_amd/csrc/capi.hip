@@ -1189,7 +1189,7 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
     E.ws_ebits = (int32_t *)((uint8_t *)ctx->ws_enc + off_ebits);
     E.ws_snr = (int32_t *)((uint8_t *)ctx->ws_enc + off_snr);
     E.ws_memo = (uint32_t *)((uint8_t *)ctx->ws_enc + off_memo);
-    if (taps && taps->d_mdct) E.ws_mdct = taps->d_mdct;
+    if (taps && taps->d_mdct) { E.ws_mdct = taps->d_mdct; E.mdct_full_rows = true; }
     if (taps && taps->d_exponent) E.ws_expo = taps->d_exponent;
     if (taps && taps->d_exp_samples) E.ws_shift = taps->d_exp_samples;
     if (taps && taps->d_encoded_exp) E.ws_eexp = taps->d_encoded_exp;      // the exponent stage writes the tap directly

@@ -574,6 +574,7 @@ struct MdctParams {
     uint8_t chmap[8];
     const int32_t *slot;        // optional: stream s keeps its history in slot[s] (stride 6*256 samples)
     int store_history;          // one frame per stream: this kernel also leaves the new history (else enc_history_kernel)
+    int full_rows;              // store all 256 coefficients of a row (stage tap); else only the bins the packer codes
     ExpParams x;                // the exponent stage that follows the transform
 };
 
@@ -785,7 +786,9 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
             }
             epack |= (uint32_t)(e & 0xff) << (8 * k);
         }
-        *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
+        // (the packers read a row's coded bins only: 223 of a full-bandwidth channel, 7 of the LFE - a quarter of the store traffic)
+        if (P.full_rows || 4 * lane < ((P.x.lfe && ch == P.nch - 1) ? 7 : P.x.nbc))
+            *reinterpret_cast<int4 *>(P.mdct + row * 256 + 4 * lane) = make_int4(cc[0], cc[1], cc[2], cc[3]);
         if (P.expo) *reinterpret_cast<uint32_t *>(P.expo + row * 256 + 4 * lane) = epack;       // tap only
         *reinterpret_cast<uint32_t *>(&XL.E[blk][4 * lane]) = epack;
         if (lane == 0) P.shift[row] = (int8_t)shift;
@@ -1748,7 +1751,9 @@ struct alignas(16) PackbLDS {
 };
 
 #ifndef ENC_PACKB_LB
-#define ENC_PACKB_LB 6
+#define ENC_PACKB_LB 4        // 128 VGPRs, 12 bytes of scratch (6: 80 VGPRs, 204 bytes).  Its batches fit the chip several times over, so a frame's latency
+                              // counts, not occupancy: cold encode 0.107 / 0.113 / 0.189 / 0.286 ms per 64 / 256 / 1 024 / 2 048 frames against 0.110 /
+                              // 0.121 / 0.186 / 0.291 at 6
 #endif
 __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const PackParams P)
 {
@@ -2163,6 +2168,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     M.pcm = E.pcm;
     M.last = E.last;
     M.mdct = E.ws_mdct;
+    M.full_rows = E.mdct_full_rows ? 1 : 0;
     M.expo = E.ws_expo;
     M.shift = E.ws_shift;
     M.tab = tab.enc;
@@ -2235,14 +2241,15 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
     // The SNR-offset searches run one wavefront per stream (PART 1; for few long streams behind PART 3's frame-parallel
     // tabulation), then every frame is packed by a workgroup of six wavefronts, one per audio block (enc_packb_kernel).
-    // Measured per call on one-frame streams, cold (profiles/encode_cold.py): 64 frames 0.147 against 0.219 ms with the
-    // one-kernel packer, 1 024: 0.222 / 0.261, 4 096: 0.599 / 0.546, 65 536: 7.9 / 7.0 - a frame's chain is a sixth as long,
-    // but a workgroup's wavefronts wait for each other five times per frame, so the chip holds fewer busy wavefronts: the
-    // block packer takes batches of up to 2 048 frames (the byte-stream layer's chunks), the one-kernel packer the rest.
+    // Measured per call on one-frame streams, cold (profiles/encode_cold.py, end of round 3): 64 frames 0.107 against 0.162 ms
+    // with one wavefront per frame, 256: 0.111 / 0.168, 512: 0.134 / 0.179, 1 024: 0.191 / 0.192, 2 048: 0.291 / 0.262,
+    // 4 096: 0.497 / 0.394, 8 192: 0.917 / 0.700 - a frame's chain is a sixth as long, but a workgroup's wavefronts wait for each
+    // other five times per frame, so the chip holds fewer busy wavefronts: the block packer takes batches of up to 1 024
+    // frames (the byte-stream layer's chunks), one wavefront per frame the rest.
     // E.pack_mode (ac3mi_set_encode_mode): 0 = that rule, 1 = never, 2 = always the block packer.
     const unsigned nfr = (unsigned)E.n_streams * (unsigned)E.frames_per_stream;
     const bool long_streams = E.frames_per_stream > 1 && E.n_streams < 5120;
-    const bool packb = E.pack_mode == 2 || (E.pack_mode == 0 && nfr <= 2048);
+    const bool packb = E.pack_mode == 2 || (E.pack_mode == 0 && nfr <= 1024);
     // Large batches of one-frame streams: search kernel (PART 1) + one wavefront per frame packs (PART 2) instead of the
     // one-kernel PART 0, whose register budget holds neither half comfortably (128 VGPRs + scratch against 98 and 97).
     // AC3MI_ENC_BIG_SPLIT=0: PART 0 (A/B runs).

@@ -158,8 +158,8 @@ int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
  *      wavefront per frame packs);
  *   2  searches per stream, then a workgroup of six wavefronts per frame, one per audio block: every block's first bit
  *      follows from bit counts, so the six pack at once into the frame they share in LDS (a third less latency per frame;
- *      ahead for batches of up to about 2 000 frames);
- *   0  (default) 2 for up to 2 048 frames per call, else 1. */
+ *      ahead for batches of up to about 1 000 frames);
+ *   0  (default) 2 for up to 1 024 frames per call, else 1. */
 int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode);
 
 /* Workspace bound (new; results do not depend on it, except for frames flagged AC3MI_STATUS_REUSE0 at a tile boundary).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
