@@ -84,9 +84,13 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
     for (int i = lane; i < 100; i += 64) L.desc[i] = mant_desc((uint32_t)i);
     if (lane < 30) L.band_end[lane] = P.tab->band_end[lane];
     for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
-    for (int i = lane; i < ROWS; i += 64) { L.exp[i] = 0; L.bap[i] = 0; }
-    for (int i = lane; i < 6 * 52; i += 64) (&L.deltba[0][0])[i] = 0;
-    for (int i = lane; i < 90; i += 64) (&L.cplco[0][0])[i] = 0.f;
+    {
+        // exp, bap, deltba and cplco are adjacent and dword-sized together: zeroed as dwords (a byte loop took 26 rounds)
+        static_assert(offsetof(DecLDS, exp) == 0 && offsetof(DecLDS, bap) == ROWS && offsetof(DecLDS, deltba) == 2 * ROWS &&
+                      offsetof(DecLDS, cplco) == 2 * ROWS + 6 * 52 && offsetof(DecLDS, gcode) == 2 * ROWS + 6 * 52 + 90 * 4 && ROWS % 4 == 0, "layout");
+        uint32_t *z = reinterpret_cast<uint32_t *>(&L);
+        for (int i = lane; i < (2 * ROWS + 6 * 52 + 90 * 4) / 4; i += 64) z[i] = 0u;
+    }
 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -138,15 +142,23 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
         {
             const int nw = (P.frame_bytes + 3) >> 2;
             const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-            for (int i = lane; i < nw + 6; i += 64) {             // (the mantissa stage reads three dwords from index <= nw + 2)
-                uint32_t v = 0;
-                if (i < nw) {
-                    v = s32[i];
-                    const int rem = P.frame_bytes - 4 * i;
-                    if (rem < 4) v &= (1u << (8 * rem)) - 1u;
-                    v = __builtin_bswap32(v);
+            // (the mantissa stage reads three dwords from index <= nw + 2.)  Eight loads in flight per lane before the first
+            // is used: a 1536-byte frame is one round instead of seven dependent ones
+            for (int base = 0; base < nw + 6; base += 512) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = base + lane + 64 * k;
+                    v[k] = i < nw ? s32[i] : 0u;
                 }
-                frw[i] = v;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = base + lane + 64 * k;
+                    const int rem = P.frame_bytes - 4 * i;
+                    uint32_t x = v[k];
+                    if (rem < 4 && rem > 0) x &= (1u << (8 * rem)) - 1u;
+                    if (i < nw + 6) frw[i] = __builtin_bswap32(x);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
