@@ -150,6 +150,8 @@ struct EncodeLaunch {
     int32_t *tap_snr;
     const int32_t *slot;
     int pack_mode = 0;          // ac3mi_set_encode_mode
+    const uint32_t *search_hint = nullptr;     // transcode: per frame, an offset 16 csnroffst + fsnroffst near which to start costing (stride in dwords)
+    int search_hint_stride = 0;
 };
 hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStream_t stream);
 hipError_t launch_enc_history(const EncodeLaunch &E, hipStream_t stream);

@@ -1404,6 +1404,11 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         G.frames_per_stream = frames_per_stream;
         G.tap_eexp = G.tap_bap = G.tap_strat = nullptr;
         G.tap_snr = nullptr;
+        if (split) {                                        // block 0's descriptor of every frame carries the source's SNR offsets
+            const SplitWs w = split_ws(ctx, nfr, f0);
+            G.search_hint = reinterpret_cast<const uint32_t *>(w.desc) + 72 / 4;         // BlkDesc::src_snr (decode_common.h asserts the offset)
+            G.search_hint_stride = 6 * 80 / 4;                                           // six 80-byte descriptors per frame
+        }
         return launch_encode(ctx->tab, G, ctx->stream);
     };
     HIPCHK(ctx, front(0));

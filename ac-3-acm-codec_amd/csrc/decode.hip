@@ -583,7 +583,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                         if (lane < 8) { dp[32 + lane] = (uint8_t)rv_exp; dp[40 + lane] = (uint8_t)rv_bap; }
                         const float gl = lane == 0 ? gain[0] : lane == 1 ? gain[1] : lane == 2 ? gain[2] : lane == 3 ? gain[3] : lane == 4 ? gain[4]
                                        : (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
-                        if (lane < 6) reinterpret_cast<float *>(dp + 48)[lane] = gl;
+                        // spare word: the frame's own SNR offsets, 16 csnroffst + fsnroffst of channel 0 - a transcode's encoder starts
+                        // costing its search there (a hint: which offsets are costed never changes a result, encode.hip)
+                        const uint32_t w12 = lane < 6 ? __float_as_uint(gl) : (uint32_t)(16 * st.csnroffst + (st.cbai[0] >> 3));
+                        if (lane < 7) reinterpret_cast<uint32_t *>(dp + 48)[lane] = w12;
                     }
                     bd_ok = true;
                 }

@@ -829,9 +829,10 @@ struct alignas(16) BlkDesc {
     uint16_t endmant[5], cplstrt, cplend, pad0;
     uint8_t rv_exp[8], rv_bap[8];   // block of THIS frame whose row holds the slot's current exponents / bap
     float gain[5], lfe_gain;        // parse.c:810-811 (dynamic range folded in); LFE: 0 when it is not an output
-    uint32_t pad1[2];
+    uint32_t src_snr;           // 16 csnroffst + fsnroffst (channel 0) the frame was coded with, as of this block
+    uint32_t pad1;
 };
-static_assert(sizeof(BlkDesc) == 80, "BlkDesc layout");
+static_assert(sizeof(BlkDesc) == 80 && offsetof(BlkDesc, src_snr) == 72, "BlkDesc layout");
 
 constexpr int ROWSET = 7 * 512;         // bytes of one (frame, block) row set: 7 slots x (256 exponents + 256 row bytes)
 

@@ -70,6 +70,8 @@ struct PackParams {
     int c1, c2;                 // CRC chunk bytes per lane
     int frw;                    // dwords of the frame buffer in (dynamic) LDS: the frame + 256 bytes of headroom, multiple of 4
     int marker;                 // the reference's "member already merged" value, 128 (:1375-1413); AC3MI_ENC_MARKER: test aid
+    const uint32_t *hint;       // optional, [frame * hint_stride]: 16 csnroffst + fsnroffst the frame's SOURCE was coded with (transcode)
+    int hint_stride;
 };
 
 
@@ -1332,6 +1334,14 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
             // rungs per sweep - the bounds above turn a rung that fails or fits by a margin into the verdict of every rung
             // beyond it.  (Which offsets are COSTED never changes a result: the reference's sequence is replayed from exact
             // verdicts only.)
+            if (n_cand == 0 && first_sweep && cold_hint && P.hint) {
+                // a transcode: decoded audio re-encoded at its source's rate lands within -5 .. +11 steps of the offsets the source
+                // frame carried: the first sweep costs around them - 3.4 -> 2.45 sweeps per frame (profiles/search_sim.py on
+                // second-generation content).  A hint far off (another target rate) costs a sweep; results never depend on it.
+                int g0 = (int)__builtin_amdgcn_readfirstlane((int)P.hint[fidx * (size_t)P.hint_stride]);
+                g0 = g0 < 8 ? 8 : g0 > 1000 ? 1000 : g0;
+                add(g0 - 8); add(g0 + 2); add(g0 + 12);
+            }
             if (n_cand == 0 && first_sweep && cold_hint) {
                 // a fresh stream's first sweep: csnroffst 8, 13 and 20, around where material lands at the usual rates (64 kbps
                 // mono to 640 kbps 5.1: boundary at 8 .. 16 1/2 in profiles/search_sim.py) - 3.8 -> 3.5 sweeps per cold frame
@@ -2236,6 +2246,8 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     }
     P.snr = E.ws_snr;
     P.memo = nullptr;
+    P.hint = E.search_hint;
+    P.hint_stride = E.search_hint_stride;
     P.frw = ((2 * fs + 256 + 15) / 16) * 4;
     P.marker = getenv("AC3MI_ENC_MARKER") ? atoi(getenv("AC3MI_ENC_MARKER")) : 128;      // test aid (read per launch), see PackParams::marker
     static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
