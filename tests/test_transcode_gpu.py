@@ -29,8 +29,11 @@ def _three_calls(engine, pkg, frames_t, dec, enc, chmap, S, F, n_out):
     return out, status, delay, lfsr, last, csnr
 
 
-@pytest.mark.parametrize("S,F", [(5, 3), (6000, 3)])
-def test_transcode_equals_the_three_calls(engine, S, F):
+@pytest.mark.parametrize("S,F,bitrate", [(5, 3, 448000), (6000, 3, 448000), (3000, 2, 224000), (3000, 2, 640000)])
+def test_transcode_equals_the_three_calls(engine, S, F, bitrate):
+    """(The large batches go through the split front end, whose descriptors carry the source frames' SNR offsets to the
+    encoder's search as a starting point; the target rates far from the source's 384 kbps make that hint a bad one:
+    it must not change a byte.)"""
     import torch
     pkg = H.pkg()
     base = [H.orc_encode(H.gen_pcm(F, 6, seed=400 + s, kind=("tones", "music", "bursts", "noise")[s % 4])) for s in range(8)]
@@ -38,7 +41,7 @@ def test_transcode_equals_the_three_calls(engine, S, F):
     fb = frames.shape[2]
     frames_t = torch.from_numpy(frames).cuda()
     dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=fb)
-    enc = pkg.EncodeDesc(48000, 448000, 6)
+    enc = pkg.EncodeDesc(48000, bitrate, 6)
     want = _three_calls(engine, pkg, frames_t, dec, enc, H.CHMAP6, S, F, 6)
     dev = frames_t.device
     delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
