@@ -111,6 +111,7 @@ def load_library():
     lib.ac3mi_set_mix_state.argtypes = [c_void_p, c_void_p, c_void_p]
     lib.ac3mi_probe_valu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_probe_salu_rate.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_double)]
+    lib.ac3mi_probe_mixed_rate.argtypes = [c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_probe_copy_rate.argtypes = [c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]
     lib.ac3mi_set_tile_frames.argtypes = [c_void_p, ctypes.c_longlong]
     lib.ac3mi_transcode_batch.argtypes = [c_void_p, ctypes.POINTER(DecodeDescC), ctypes.POINTER(EncodeDescC), c_void_p, ctypes.c_int,

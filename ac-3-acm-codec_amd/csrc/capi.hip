@@ -379,6 +379,24 @@ __global__ __launch_bounds__(256) void salu_probe_kernel(uint32_t *out, int iter
     }
     if ((s0 ^ s1 ^ s2 ^ s3) == 0x12345678u) out[0] = s0;
 }
+// both at once, three vector instructions to one scalar one (the encoder's and the front end's mix): iters x (24 + 8) per wavefront
+__global__ __launch_bounds__(256) void mixed_probe_kernel(uint32_t *out, int iters)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    const uint32_t k = blockIdx.x | 1u;
+    for (int i = 0; i < iters; i++) {
+#define AC3MI_MIX4 "v_add_u32 %0, %0, %10\n v_xor_b32 %1, %1, %10\n v_add_u32 %2, %2, %10\n s_add_u32 %6, %6, 1\n" \
+                   "v_xor_b32 %3, %3, %10\n v_add_u32 %4, %4, %10\n v_xor_b32 %5, %5, %10\n s_xor_b32 %7, %7, 3\n" \
+                   "v_add_u32 %0, %0, %10\n v_xor_b32 %1, %1, %10\n v_add_u32 %2, %2, %10\n s_add_u32 %8, %8, 5\n" \
+                   "v_xor_b32 %3, %3, %10\n v_add_u32 %4, %4, %10\n v_xor_b32 %5, %5, %10\n s_xor_b32 %9, %9, 7\n"
+        asm volatile(AC3MI_MIX4 AC3MI_MIX4
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+                     : "v"(k) : "scc");
+#undef AC3MI_MIX4
+    }
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ s0 ^ s1 ^ s2 ^ s3) == 0x12345678u) out[0] = a0;
+}
 }  // namespace ac3mi
 
 extern "C" {
@@ -618,6 +636,28 @@ int ac3mi_probe_salu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd)
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     (void)hipFree(d);
     *ginst_per_s_per_simd = (double)wg_per_cu * iters * 32.0 / (ms * 1e-3) / 1e9;
+    return AC3MI_OK;
+}
+
+int ac3mi_probe_mixed_rate(ac3mi_ctx *ctx, int waves_per_simd, double *valu_ginst_per_s_per_simd, double *salu_ginst_per_s_per_simd)
+{
+    if (!ctx || !valu_ginst_per_s_per_simd || !salu_ginst_per_s_per_simd || waves_per_simd < 1 || waves_per_simd > 8) return AC3MI_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int cus = prop.multiProcessorCount, wg_per_cu = waves_per_simd, iters = 8192;      // a 256-thread workgroup = one wavefront per SIMD
+    uint32_t *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, 64));
+    hipLaunchKernelGGL(mixed_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, 64);      // warm-up
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(mixed_probe_kernel, dim3(cus * wg_per_cu), dim3(256), 0, ctx->stream, d, iters);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    (void)hipFree(d);
+    *valu_ginst_per_s_per_simd = (double)wg_per_cu * iters * 24.0 / (ms * 1e-3) / 1e9;
+    *salu_ginst_per_s_per_simd = (double)wg_per_cu * iters * 8.0 / (ms * 1e-3) / 1e9;
     return AC3MI_OK;
 }
 

@@ -234,6 +234,13 @@ class Engine:
         self._check(self.lib.ac3mi_probe_salu_rate(ctypes.c_void_p(self.ctx), ctypes.byref(v)))
         return v.value
 
+    def probe_mixed_rate(self, waves_per_simd=8):
+        """(vector, scalar) 10^9 instructions/s per SIMD when every wavefront issues three vector instructions per scalar one
+        (ac3mi_probe_mixed_rate)."""
+        v, s = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.ac3mi_probe_mixed_rate(ctypes.c_void_p(self.ctx), int(waves_per_simd), ctypes.byref(v), ctypes.byref(s)))
+        return v.value, s.value
+
     def set_tile_frames(self, frames):
         """Workspace bound: batches above `frames` frames go through in tiles of whole streams (ac3mi_set_tile_frames)."""
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))

@@ -379,6 +379,12 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=Tr
     res["valu_probe"] = {"ginst_per_s_per_simd": rate,
                          "note": "plain 32-bit VALU instructions one SIMD sustains with all SIMDs busy (8 wavefronts each); "
                                  "the valu_issue rooflines of the legs are priced against this x %d SIMDs" % N_SIMD}
+    # ... and what the two pipes sustain TOGETHER at the integer kernels' own mix (three vector instructions per scalar one) and
+    # occupancies: the vector pipe reaches its own ceiling only at 8 wavefronts per SIMD; the scalar stream rides along
+    res["mixed_probe"] = {"note": "10^9 (vector, scalar) instructions per second and SIMD, every wavefront issuing 3 vector per scalar instruction "
+                                  "on independent registers (ac3mi_probe_mixed_rate); the packers run 4 wavefronts per SIMD, the parse kernel 5, "
+                                  "enc_mdct_kernel 7, mant_kernel 8",
+                          "by_wavefronts_per_simd": {str(w): list(eng.probe_mixed_rate(w)) for w in (4, 5, 6, 7, 8)}}
     mix = instruction_mix()
     for name in ("encode", "decode", "decode_s16", "transcode", "transform_downmix_mixed_blocks"):
         res[name]["roofline"] = leg_rooflines(name, res[name]["algorithmic_bytes_per_frame"], res[name]["frames_per_s_per_gpu"], rate, mix, srate)

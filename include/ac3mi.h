@@ -83,6 +83,10 @@ int ac3mi_probe_valu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd);
 /* the same for scalar (SALU) instructions: the scalar unit issues about half as fast as a SIMD's vector pipe, so for the
  * front ends and the packer - a third or more of whose instructions are scalar - it is the tighter of the two ceilings */
 int ac3mi_probe_salu_rate(ac3mi_ctx *ctx, double *ginst_per_s_per_simd);
+/* both at once: every wavefront issues three vector instructions per scalar one (the mix of the encoder and the decode front
+ * end), `waves_per_simd` (1..8) wavefronts per SIMD: the two rates it sustains together.  If they added up to the rates above the
+ * two pipes would overlap perfectly; DESIGN.md 4.3 prices the integer kernels with what this measures. */
+int ac3mi_probe_mixed_rate(ac3mi_ctx *ctx, int waves_per_simd, double *valu_ginst_per_s_per_simd, double *salu_ginst_per_s_per_simd);
 /* Measurement aid: the rate (read + written GB/s) of a bare float4 copy of `bytes` bytes, one element per lane - the copy
  * MI355X_MICROARCH.md quotes for this part; bench.py reports the transform's rate next to it.  Allocates 2 x bytes. */
 int ac3mi_probe_copy_rate(ac3mi_ctx *ctx, size_t bytes, double *gbytes_per_s);
