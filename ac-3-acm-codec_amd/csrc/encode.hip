@@ -987,6 +987,10 @@ __device__ unsigned long long g_pack_cycles[8];
 #define ENC_NC 3
 #endif
 
+// what a grouped mantissa is to its code, by 3 x kind + member (3-, 5-level: members 0..2; 11-level: 0..1; ungrouped: nothing):
+// 3-bit entries, 1 = opens the code, 2 = its last member, 4 = a later member
+#define AC3MI_GROUP_FLAGS (1u | 4u << 3 | 6u << 6 | 1u << 9 | 4u << 12 | 6u << 15 | 1u << 18 | 6u << 21)
+
 #ifndef ENC_PACK_LB
 #define ENC_PACK_LB 4            // wavefronts per SIMD the packer's register budget is set for (128 VGPRs; at 5 the branch-free mantissa passes spill: 6.26 vs 6.09 ms per 65 536 frames)
 #endif
@@ -1530,7 +1534,9 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
                 int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
-                uint32_t baseg = 0, basem = 0;      // the same as (codes opened mod 256) << 8 kind and (members of the open code) << 2 kind
+                // per kind (10-bit fields at 0 / 10 / 20): (codes opened so far mod the kind's ring) x members per code + members of the
+                // open code = the block's count mod 384 / 384 / 512.  A pass's ranks start there, so rank / members IS the ring slot.
+                uint32_t phase = 0;
                 int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
                 uint32_t *const sink = &L.gtab[512 + 2 * lane];
                 // The LFE's seven coefficients ride in the LAST full-bandwidth channel's pass: that channel's 223 bins fill
@@ -1589,33 +1595,31 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         }
                     }
                     const uint32_t gin = wave_incl_scan_u32(cnt_lane);
-                    uint32_t run = gin - cnt_lane;                          // ranks inside the pass of the lane's next bin, per kind
+                    uint32_t run = gin - cnt_lane + phase;                          // ranks inside the pass of the lane's next bin, per kind
                     uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
                     uint32_t bits_lane = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
-                        const uint32_t r = ((run >> sh) & 1023u) + ((basem >> (2 * kind)) & 3u);    // rank counted from the open code's first member
+                        const uint32_t r = (run >> sh) & 1023u;                                    // rank counted from the ring's slot 0 (see `phase`)
                         run += 1u << sh;
                         const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
                         const uint32_t gl = kind < 2 ? by3 : by2;                                  // r / 3 or r / 2 (both computed: a select, not a branch)
                         const uint32_t per = 3u - (kind >> 1);
-                        const uint32_t idx = 4 * kind + (r - gl * per);                            // (kind, member)
-                        const uint32_t opens = (0x0111u >> idx) & 1u, last = (0x0244u >> idx) & 1u, member = (0x0266u >> idx) & 1u;
-                        const uint32_t grp = ((baseg >> (8 * kind)) & 255u) + gl;
-                        const uint32_t ring = 128u * kind + (grp & (127u | ((kind & 2u) << 6)));
+                        const uint32_t idx = 3u * kind + (r - gl * per);                           // (kind, member)
+                        const uint32_t F = __builtin_amdgcn_ubfe(AC3MI_GROUP_FLAGS, 3u * idx, 3u);   // 1 opens, 2 last, 4 member
+                        const uint32_t ring = 128u * kind + (gl & (127u | ((kind & 2u) << 6)));
                         slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
                         const uint32_t gbits = (pw[j] >> 7) & 7u;
-                        const uint32_t keep = opens;
-                        nb[j] = w + gbits * keep;
+                        nb[j] = w + gbits * (F & 1u);
                         bits_lane += nb[j];
-                        fl[j] = opens | (last << 1) | (member << 2) | (gbits << 4) | (gl << 8);
+                        fl[j] = F | (gbits << 4) | (gl << 8);
                         // quantise (:1150-1190)
                         const int levels = (int)((pw[j] >> 10) & 15u);
                         const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
                         const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
                         const int q = ((pw[j] >> 14) & 1u) ? vs : va;
-                        const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
+                        const int wgt = (F & 2u) ? 1 : (F & 1u) ? (int)((pw[j] >> 15) & 31u) : levels;
                         vq[j] = (uint32_t)q & 0xffffu;
                         vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;     // (only the product's low 16 bits count: a 24-bit multiply, not the quarter-rate 32-bit one)
                     }
@@ -1623,7 +1627,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const uint32_t kind = (pw[j] >> 5) & 3u;
-                            const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                            const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
                             const uint32_t key = (kind << 16) | full;
                             bool dropped = false;
                             for (int q = 0; q < dropped_known; q++) dropped |= L.coll[q] == key;
@@ -1660,7 +1664,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         for (int j = 0; j < 4; j++)
                             if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
                                 const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
-                                const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                                const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
                                 const int q = atomicAdd(&L.ncoll, 1);
                                 if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | full;
                             }
@@ -1670,8 +1674,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         const uint32_t gtot = wave_last(gin);
                         const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
                         b3 += t3; b5 += t5; b11 += t11;
-                        baseg = (uint32_t)((b3 / 3) & 255) | ((uint32_t)((b5 / 3) & 255) << 8) | ((uint32_t)((b11 >> 1) & 255) << 16);
-                        basem = (uint32_t)(b3 % 3) | ((uint32_t)(b5 % 3) << 2) | ((uint32_t)(b11 & 1) << 4);
+                        phase = (uint32_t)(b3 % 384) | ((uint32_t)(b5 % 384) << 10) | ((uint32_t)(b11 & 511) << 20);
                     }
                     pos += wave_last(bin_);
                 }
@@ -1952,7 +1955,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         {
             const uint32_t marker = (uint32_t)P.marker;
             int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
-            uint32_t baseg = 0, basem = 0;
+            uint32_t phase = 0;                 // see enc_pack_kernel
             int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
             uint32_t *const sink = &W.gtab[512 + 2 * lane];
             // the LFE's seven coefficients ride in the last full-bandwidth channel's pass (lanes 56..62): see enc_pack_kernel
@@ -2004,31 +2007,30 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
                     }
                 }
                 const uint32_t gin = wave_incl_scan_u32(cnt_lane);
-                uint32_t run = gin - cnt_lane;
+                uint32_t run = gin - cnt_lane + phase;
                 uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
                 uint32_t bits_lane = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
-                    const uint32_t r = ((run >> sh) & 1023u) + ((basem >> (2 * kind)) & 3u);
+                    const uint32_t r = (run >> sh) & 1023u;
                     run += 1u << sh;
                     const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
                     const uint32_t gl = kind < 2 ? by3 : by2;
                     const uint32_t per = 3u - (kind >> 1);
-                    const uint32_t idx = 4 * kind + (r - gl * per);
-                    const uint32_t opens = (0x0111u >> idx) & 1u, last = (0x0244u >> idx) & 1u, member = (0x0266u >> idx) & 1u;
-                    const uint32_t grp = ((baseg >> (8 * kind)) & 255u) + gl;
-                    const uint32_t ring = 128u * kind + (grp & (127u | ((kind & 2u) << 6)));
+                    const uint32_t idx = 3u * kind + (r - gl * per);
+                    const uint32_t F = __builtin_amdgcn_ubfe(AC3MI_GROUP_FLAGS, 3u * idx, 3u);
+                    const uint32_t ring = 128u * kind + (gl & (127u | ((kind & 2u) << 6)));
                     slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
                     const uint32_t gbits = (pw[j] >> 7) & 7u;
-                    nb[j] = w + gbits * opens;
+                    nb[j] = w + gbits * (F & 1u);
                     bits_lane += nb[j];
-                    fl[j] = opens | (last << 1) | (member << 2) | (gbits << 4) | (gl << 8);
+                    fl[j] = F | (gbits << 4) | (gl << 8);
                     const int levels = (int)((pw[j] >> 10) & 15u);
                     const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
                     const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
                     const int q = ((pw[j] >> 14) & 1u) ? vs : va;
-                    const int wgt = last ? 1 : opens ? (int)((pw[j] >> 15) & 31u) : levels;
+                    const int wgt = (F & 2u) ? 1 : (F & 1u) ? (int)((pw[j] >> 15) & 31u) : levels;
                     vq[j] = (uint32_t)q & 0xffffu;
                     vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;
                 }
@@ -2036,7 +2038,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t kind = (pw[j] >> 5) & 3u;
-                        const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                        const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
                         const uint32_t key = (kind << 16) | full;
                         bool dropped = false;
                         for (int q = 0; q < dropped_known; q++) dropped |= W.coll[q] == key;
@@ -2070,7 +2072,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
                     for (int j = 0; j < 4; j++)
                         if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
                             const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
-                            const uint32_t full = (uint32_t)(kind == 0 ? b3 / 3 : kind == 1 ? b5 / 3 : b11 >> 1) + (fl[j] >> 8);
+                            const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
                             const int q = atomicAdd(&W.ncoll, 1);
                             if (q < 32) W.coll[q] = ((uint32_t)kind << 16) | full;
                         }
@@ -2080,8 +2082,7 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
                     const uint32_t gtot = wave_last(gin);
                     const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
                     b3 += t3; b5 += t5; b11 += t11;
-                    baseg = (uint32_t)((b3 / 3) & 255) | ((uint32_t)((b5 / 3) & 255) << 8) | ((uint32_t)((b11 >> 1) & 255) << 16);
-                    basem = (uint32_t)(b3 % 3) | ((uint32_t)(b5 % 3) << 2) | ((uint32_t)(b11 & 1) << 4);
+                    phase = (uint32_t)(b3 % 384) | ((uint32_t)(b5 % 384) << 10) | ((uint32_t)(b11 & 511) << 20);
                 }
                 pos += wave_last(bin_);
             }
