@@ -84,8 +84,11 @@ struct MaskTabs {
     uint8_t band_start[52];
 };
 
-struct alignas(16) PackLDS {
-    int16_t mask[36][50];       // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
+// MASK_ROWS: 36 where a frame's search needs every (block, channel) curve at once; 6 in the kernel that only packs (PART 2): it
+// loads a block's rows when it gets there, which brings its LDS from 9.8 to 6.8 KB - a fifth wavefront per SIMD
+template <int MASK_ROWS>
+struct alignas(16) PackLDS_T {
+    int16_t mask[MASK_ROWS][50];        // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
     uint32_t gtab[640];         // 3/5/11-level codes being assembled, rings of 128 / 128 / 256: bit offset | 16-bit code << 16; from 512 on two
                                 // sink words per lane: where stores, adds and put_bits_always of lanes with nothing to say go
     uint32_t bitlut[64];        // see lut_index
@@ -104,6 +107,7 @@ struct alignas(16) PackLDS {
     // exponents (bits 0-13) | LFE row (7 coefficients, bit 14) | blocks the run covers (bits 16-21) | mask row (24-29)
     uint32_t rowdesc[36];
 };
+typedef PackLDS_T<36> PackLDS;
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
 // the bits before the field as far as the 32-bit word it starts in, which is what the 64-bit shift below does.
@@ -997,10 +1001,14 @@ __device__ unsigned long long g_pack_cycles[8];
 #ifndef ENC_SEARCH_LB
 #define ENC_SEARCH_LB ENC_PACK_LB
 #endif
+#ifndef ENC_PACK2_LB
+#define ENC_PACK2_LB 5           // the packing-only kernel: 96 VGPRs (20 bytes of scratch) and 6.8 KB of LDS with a block's mask rows at a time: 2.17 ms
+                                // per 65 536 frames against 2.25 at 4 per SIMD with every row resident (2.28 at 4 with the rows per block)
+#endif
 template <int PART>
-__global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PACK2_LB : ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
 {
-    __shared__ PackLDS L;
+    __shared__ PackLDS_T<(PART == 2 ? 6 : 36)> L;
     extern __shared__ uint4 pk_dyn[];
     uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
     const int lane = threadIdx.x;
@@ -1049,7 +1057,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
             loaded = true;
         // ---- masking curves, strategies and exponent bit counts from exp_stage (the encoded exponents
             //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
-            {
+            if (PART != 2) {                         // (PART 2: a block's rows when the block is packed)
                 const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
                 uint32_t mv[15];
 #pragma unroll
@@ -1062,8 +1070,8 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                     const int i = lane + 64 * j;
                     if (i < 6 * nch * 25) reinterpret_cast<uint32_t *>(&L.mask[0][0])[i] = mv[j];
                 }
-                if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             }
+            if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
             if (PART == 0 || PART == 2)
                 for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
@@ -1465,6 +1473,15 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
             uint32_t ew[6];
 #pragma unroll
             for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane) : 0u;
+            if (PART == 2) {                            // this block's mask rows (25 dwords per channel), in flight during the side information
+                const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + (fidx * 6 + b) * nch * 50);
+                uint32_t mv[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) mv[j] = lane + 64 * j < nch * 25 ? gm[lane + 64 * j] : 0u;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (lane + 64 * j < nch * 25) reinterpret_cast<uint32_t *>(&L.mask[0][0])[lane + 64 * j] = mv[j];
+            }
             flush();
             for (int ch = 0; ch < nfbw; ch++) put(1, 0);
             for (int ch = 0; ch < nfbw; ch++) put(1, 1);
@@ -1560,7 +1577,8 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                     }
                     const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
                     const bool lfe_lane = merged && lk >= 0;
-                    const int16_t *Mr = &L.mask[b * nch + ch][0];
+                    const int mrow0 = PART == 2 ? 0 : b * nch;              // (PART 2 holds the block's rows only)
+                    const int16_t *Mr = &L.mask[mrow0 + ch][0];
                     int shv = (int)L.shiftv[b * 6 + ch];
                     uint32_t bands = bandoff;
                     if (merged) {
@@ -1570,7 +1588,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : ENC_PACK_LB) void e
                         const uint32_t lexp = ((uint32_t)__shfl((int)le, lk >= 0 ? lk >> 2 : 0, 64) >> (8 * (lk & 3))) & 0xffu;
                         e4 = lfe_lane ? lexp : e4;
                         c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
-                        Mr = lfe_lane ? &L.mask[b * nch + nch - 1][0] : Mr;
+                        Mr = lfe_lane ? &L.mask[mrow0 + nch - 1][0] : Mr;
                         shv = lfe_lane ? (int)L.shiftv[b * 6 + nch - 1] : shv;
                         bands = lfe_lane ? (uint32_t)lk : bands;              // (LFE bins 0..6 are bands 0..6)
                     }
@@ -2249,7 +2267,10 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.memo = nullptr;
     P.hint = E.search_hint;
     P.hint_stride = E.search_hint_stride;
-    P.frw = ((2 * fs + 256 + 15) / 16) * 4;
+#ifndef ENC_FR_HEADROOM
+#define ENC_FR_HEADROOM 256
+#endif
+    P.frw = ((2 * fs + ENC_FR_HEADROOM + 15) / 16) * 4;
     P.marker = getenv("AC3MI_ENC_MARKER") ? atoi(getenv("AC3MI_ENC_MARKER")) : 128;      // test aid (read per launch), see PackParams::marker
     static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
     const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
