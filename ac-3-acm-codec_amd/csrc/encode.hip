@@ -23,6 +23,7 @@
 #include "ac3mi_internal.h"
 #include "wave_ops.h"
 #include "spec_tables.h"
+#include "enc_mant.h"
 
 namespace ac3mi {
 
@@ -84,30 +85,16 @@ struct MaskTabs {
     uint8_t band_start[52];
 };
 
-// MASK_ROWS: 36 where a frame's search needs every (block, channel) curve at once; 6 in the kernel that only packs (PART 2): it
-// loads a block's rows when it gets there, which brings its LDS from 9.8 to 6.8 KB - a fifth wavefront per SIMD
-template <int MASK_ROWS>
-struct alignas(16) PackLDS_T {
-    int16_t mask[MASK_ROWS][50];        // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
-    uint32_t gtab[640];         // 3/5/11-level codes being assembled, rings of 128 / 128 / 256: bit offset | 16-bit code << 16; from 512 on two
-                                // sink words per lane: where stores, adds and put_bits_always of lanes with nothing to say go
+// The search kernel's LDS: the frame's 36 masking curves, the cost table and the list of run-start rows.
+struct alignas(16) SearchLDS {
+    int16_t mask[36][50];       // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
     uint32_t bitlut[64];        // see lut_index
-    uint32_t packlut[64];       // the packing sweep's view of the same address: see pack_word
-    alignas(4) uint8_t erow[256];       // encoded exponents of the channel whose exponent groups are being packed
-    // (the frame itself, MSB-first dwords + 256 bytes of headroom for the overshoot quirk, is dynamic LDS: PackParams::frw)
-    int8_t shiftv[36];          // exp_samples of the frame
     uint8_t strat[6][6];
     uint8_t band_of_bin[256];
-    alignas(4) uint16_t crc_tab[256];
-    // grouped codes whose 16-bit value came out as 128, the reference's "member already merged" marker (:1466-1480):
-    // kind << 16 | group, first attempt of a block's packing
-    uint32_t coll[32];
-    int ncoll;
     // the frame's run-start rows in (block, channel) order, for the search's sweeps: byte offset of the row's encoded
     // exponents (bits 0-13) | LFE row (7 coefficients, bit 14) | blocks the run covers (bits 16-21) | mask row (24-29)
     uint32_t rowdesc[36];
 };
-typedef PackLDS_T<36> PackLDS;
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
 // the bits before the field as far as the 32-bit word it starts in, which is what the 64-bit shift below does.
@@ -808,17 +795,6 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
 // bap of one coefficient for SNR offset `snroffset` (:393-420):
 //   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
 //   =>  address = clamp(80 - 4 exp - max(0, (mask - floor - snroffset) >> 5), 0, 63)       (floor = 0x1f0)
-// the same without a branch: a field of no bits (or outside the frame) goes to the lane's own sink words (atomics of a
-// whole wavefront on ONE address would be served one lane after the other)
-__device__ __forceinline__ void put_bits_always(uint32_t *fr, int frw, uint32_t *sink, uint32_t pos, int n, uint32_t v)
-{
-    const int n_in = (pos >> 5) + 1 < (uint32_t)frw ? n : 0;
-    uint32_t *dst = n_in > 0 ? fr + (pos >> 5) : sink;
-    const uint64_t x = (uint64_t)v << ((64 - n - (int)(pos & 31)) & 63);
-    atomicOr(dst, (uint32_t)(x >> 32));
-    atomicOr(dst + 1, (uint32_t)x);
-}
-
 // L.bitlut[address] = plain mantissa width | (bap==1) << 9 | (bap==2) << 14 | (bap==4) << 19: 24 bits, so that a lane's sums
 // over a frame's rows (width <= 6 x 4 x 16 = 384, counts <= 24) stay clear of each other and a sum can be added to a block's
 // account with one v_mad_u32_u24.
@@ -853,21 +829,6 @@ __device__ __forceinline__ pk2 lut_index2(int d4, int mask_minus_floor, pk2 snro
 __device__ __forceinline__ int plain_bits(int bp)
 {
     return bp == 3 ? 3 : bp == 5 ? 4 : bp == 14 ? 14 : bp == 15 ? 16 : bp >= 6 ? bp - 1 : 0;
-}
-
-// What the packing sweep needs to know about a bap code, as fields of one word, so that the sweep is integer arithmetic on
-// registers instead of compares (every combined per-lane condition costs scalar mask instructions):
-//   0-4 plain bits   5-6 kind (0/1/2 = member of a 3-/5-/11-level code, 3 = not grouped)   7-9 bits of a grouped code
-//   10-13 levels of the symmetric quantiser   14 symmetric   15-19 weight of a code's first member   20-23 bap
-//   24-28 10 * kind (position of the kind's counter in the packed rank word)
-__device__ __forceinline__ uint32_t pack_word(int bp)
-{
-    const uint32_t kind = bp == 1 ? 0u : bp == 2 ? 1u : bp == 4 ? 2u : 3u;
-    const uint32_t gbits = kind == 0 ? 5u : kind < 3 ? 7u : 0u;
-    const uint32_t levels = bp == 1 ? 3u : bp == 2 ? 5u : bp == 4 ? 11u : bp == 3 ? 7u : 15u;
-    const uint32_t sym = (kind < 3 || bp == 3 || bp == 5) ? 1u : 0u;
-    const uint32_t w0 = kind == 0 ? 9u : kind == 1 ? 25u : kind == 2 ? 11u : 1u;
-    return (uint32_t)plain_bits(bp) | (kind << 5) | (gbits << 7) | (levels << 10) | (sym << 14) | (w0 << 15) | ((uint32_t)bp << 20) | ((10u * kind) << 24);
 }
 
 // The reference's SNR-offset search (:921-967) as a resumable state machine: next() skips the steps that
@@ -910,26 +871,6 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :15
     return c;
 }
 
-__device__ __forceinline__ int quant_sym(int c, int e, int levels)       // :1150-1166
-{
-    // out of contract when e < 0 (a reuse run pulled the exponent below the block's shift): as the x86 build runs it -
-    // shift count masked to 5 bits, 32-bit wrap-around multiply, arithmetic right shift
-    const uint32_t a = (uint32_t)(c >= 0 ? c : -c) << (e & 31);
-    int v = (int32_t)((uint32_t)levels * a) >> 24;
-    v = (v + 1) >> 1;
-    return c >= 0 ? (levels >> 1) + v : (levels >> 1) - v;
-}
-__device__ __forceinline__ int quant_asym(int c, int e, int qbits)       // :1169-1190
-{
-    const int lshift = e + qbits - 24;
-    const int up = (int)((unsigned)c << (lshift & 31)), down = c >> ((-lshift) & 31);      // both, then a select: no branch
-    int v = lshift >= 0 ? up : down;
-    v = (v + 1) >> 1;
-    const int m = 1 << (qbits - 1);
-    if (v >= m) v = m - 1;
-    return v & ((1 << qbits) - 1);
-}
-
 // CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
 // bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
 // a * t[0] in GF(2)[x]/poly for a table t[i] = t[0] * x^i mod poly (wave-uniform, from the kernel arguments)
@@ -968,15 +909,16 @@ __device__ uint32_t region_crc(const LDS &L, const uint32_t *fr, int end, int le
 // from those tables - costing an offset itself only when the table has no answer - and leaves csnroffst / fsnroffst
 // of every frame in P.snr; PART 2 (one wavefront per frame) packs all frames at once.
 // Measurement aid (make EXTRA=-DPACK_STAMPS, a separate library): lane 0 of every wavefront adds the s_memtime cycles it
-// spent in each section of a frame to g_pack_cycles: 0 frame set-up + SNR-offset search, 1 header / side information /
-// exponent groups, 2 mantissas, 3 CRCs + store, 4 = calls of cost_and_record, 5 = frames.  ac3mi_debug_pack_cycles reads them.
+// spent in each section of a frame to g_pack_cycles: search kernel: 0 frame set-up + SNR-offset search, 4 = calls of
+// cost_and_record, 5 = frames; enc_packf_kernel: 6 set-up, 1 header / side information / exponent groups, 2 mantissas, 3 CRCs +
+// store, 7 = frames.  ac3mi_debug_pack_cycles reads them.
 #ifdef PACK_STAMPS
-__device__ unsigned long long g_pack_cycles[8];
-#define PK_DECL() unsigned long long pk_t = 0, pk_acc[6] = {0, 0, 0, 0, 0, 0}
+__device__ unsigned long long g_pack_cycles[16];
+#define PK_DECL() unsigned long long pk_t = 0, pk_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PK_T0() pk_t = __builtin_readcyclecounter()
 #define PK_LAP(id) do { const unsigned long long t_ = __builtin_readcyclecounter(); pk_acc[id] += t_ - pk_t; pk_t = t_; } while (0)
 #define PK_COUNT(id) pk_acc[id] += 1
-#define PK_END() do { if (lane == 0) for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_pack_cycles[i_], pk_acc[i_]); } while (0)
+#define PK_END() do { if (lane == 0) for (int i_ = 0; i_ < 9; i_++) atomicAdd(&g_pack_cycles[i_], pk_acc[i_]); } while (0)
 #else
 #define PK_DECL() do { } while (0)
 #define PK_T0() do { } while (0)
@@ -991,54 +933,35 @@ __device__ unsigned long long g_pack_cycles[8];
 #define ENC_NC 3
 #endif
 
-// what a grouped mantissa is to its code, by 3 x kind + member (3-, 5-level: members 0..2; 11-level: 0..1; ungrouped: nothing):
-// 3-bit entries, 1 = opens the code, 2 = its last member, 4 = a later member
-#define AC3MI_GROUP_FLAGS (1u | 4u << 3 | 6u << 6 | 1u << 9 | 4u << 12 | 6u << 15 | 1u << 18 | 6u << 21)
-
-#ifndef ENC_PACK_LB
-#define ENC_PACK_LB 4            // wavefronts per SIMD the packer's register budget is set for (128 VGPRs; at 5 the branch-free mantissa passes spill: 6.26 vs 6.09 ms per 65 536 frames)
-#endif
 #ifndef ENC_SEARCH_LB
-#define ENC_SEARCH_LB ENC_PACK_LB
+#define ENC_SEARCH_LB 4          // 128 VGPRs; a fifth wavefront per SIMD (96 VGPRs, 28 bytes of scratch) measured the same 1.02 ms
 #endif
-#ifndef ENC_PACK2_LB
-#define ENC_PACK2_LB 5           // the packing-only kernel: 96 VGPRs (20 bytes of scratch) and 6.8 KB of LDS with a block's mask rows at a time: 2.17 ms
-                                // per 65 536 frames against 2.25 at 4 per SIMD with every row resident (2.28 at 4 with the rows per block)
-#endif
+// enc_search_kernel<1>: one wavefront per stream, frames in order; <3>: one wavefront per frame tabulates (see above).
 template <int PART>
-__global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PACK2_LB : ENC_PACK_LB) void enc_pack_kernel(const PackParams P)
+__global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const PackParams P)
 {
-    __shared__ PackLDS_T<(PART == 2 ? 6 : 36)> L;
-    extern __shared__ uint4 pk_dyn[];
-    uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
+    static_assert(PART == 1 || PART == 3, "the packers are enc_packf_kernel / enc_packb_kernel");
+    __shared__ SearchLDS L;
     const int lane = threadIdx.x;
-    constexpr bool PER_FRAME = PART == 2 || PART == 3;
+    constexpr bool PER_FRAME = PART == 3;
     const int s = PER_FRAME ? (int)(blockIdx.x / (unsigned)P.frames_per_stream) : (int)blockIdx.x;
     const int f_first = PER_FRAME ? (int)(blockIdx.x - (unsigned)s * (unsigned)P.frames_per_stream) : 0;
     const int f_end = PER_FRAME ? f_first + 1 : P.frames_per_stream;
     if (s >= P.n_streams) return;
 
-    // (byte loop kept: copying the two tables as dwords measured 4 % SLOWER for enc_pack_kernel<2>, 2.31 against 2.21 ms, same
-    // registers and LDS - code placement, not work)
-    for (int i = lane; i < 256; i += 64) {
-        L.band_of_bin[i] = P.tab->band_of_bin[i];
-        L.crc_tab[i] = P.tab->crc_tab[i];
-    }
+    for (int i = lane; i < 256; i += 64) L.band_of_bin[i] = P.tab->band_of_bin[i];
     {
         const int bp = P.tab->baptab[lane];
         L.bitlut[lane] = (uint32_t)plain_bits(bp) | ((bp == 1) << 9) | ((bp == 2) << 14) | ((bp == 4) << 19);
-        L.packlut[lane] = pack_word(bp);
     }
 
-    // fixed allocation codes (:861-879)
-    const int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
     const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
     const int fs = P.frame_words;
 
     const int sslot = P.slot ? P.slot[s] : s;
     // the stream's search state: csnroffst in bits 0-7, the fsnroffst of its last coded frame in bits 8-11 (what the
     // reference's s->csnroffst / s->fsnroffst[] hold between frames, ENC/ac3enc.cpp:969-972)
-    const int state_in = PART == 2 ? 0 : P.csnr_state[sslot];
+    const int state_in = P.csnr_state[sslot];
     int csnr_prev = state_in & 0xff, fsnr_prev = (state_in >> 8) & 15;
     PK_DECL();
 
@@ -1046,9 +969,6 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
         const size_t fidx = (size_t)s * P.frames_per_stream + f;
         PK_T0();
         PK_COUNT(5);
-        const int32_t *md = P.mdct + fidx * 6 * nch * 256;
-        const int8_t *sh = P.shift + fidx * 6 * nch;
-
         const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
         int frame_bits = 0;
         uint64_t run_starts = 0, row_set = 0;
@@ -1057,7 +977,7 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
             loaded = true;
         // ---- masking curves, strategies and exponent bit counts from exp_stage (the encoded exponents
             //      stay in HBM/L2: [blk][ch][256] bytes at `ex`) ----
-            if (PART != 2) {                         // (PART 2: a block's rows when the block is packed)
+            {
                 const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + fidx * 6 * nch * 50);
                 uint32_t mv[15];
 #pragma unroll
@@ -1073,14 +993,6 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
             }
             if (lane < 6 * nch) { const int b = lane / nch, ch = lane - b * nch; L.strat[b][ch] = P.strat[fidx * 6 * nch + lane]; }
             frame_bits = wave_sum(lane < nch ? P.ebits[fidx * nch + lane] : 0);
-            if (PART == 0 || PART == 2)
-                for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
-            WAVE_SYNC();
-
-            if (lane < 36) {
-                const int b = lane / 6, ch = lane - 6 * b;
-                L.shiftv[lane] = ch < nch ? sh[b * nch + ch] : 0;
-            }
             WAVE_SYNC();
             // rows (blk * 6 + ch) that send new exponents, i.e. start a run, as a bit set; and the same as bit 8*ch + b
             {
@@ -1123,12 +1035,6 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
         //      and everything after the first surprise is discarded. ----
         const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&L.band_of_bin[4 * lane]);    // bands of bins 4*lane..+3
         SnrSearch ss{csnr_prev, 0, 0, false};
-        int alloc_override = -1;        // PART 2: the allocation offset of a frame whose search failed (see below)
-        if (PART == 2) {                // PART 1 found them
-            const int w1 = P.snr[fidx * 2 + 1];
-            ss.csnr = P.snr[fidx * 2]; ss.fsnr = w1 & 15; ss.phase = 5;
-            if (w1 & 0x100) alloc_override = w1 >> 9;
-        }
         // Verdicts already known for this frame: bit cc of known_c / fits_c for (cc, fsnroffst 0), bit ff of
         // known_f / fits_f for (csnroffst f_cc, ff > 0).  The reference asks for some offsets twice.
         uint64_t known_c = 0, fits_c = 0;
@@ -1410,9 +1316,8 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
             continue;
         }
         int csnr = ss.csnr, fsnr = ss.fsnr;
-        int snroffset = (((csnr - 15) << 4) + fsnr) << 2;
-        int failed_alloc = alloc_override;
-        if (PART != 2) {
+        int failed_alloc = -1;
+        {
             if (!ss.failed) { csnr_prev = csnr; fsnr_prev = fsnr; }
             else {
                 // The reference's error path ("Yack, Error !!!", :930-933), reached when the start value and every start value
@@ -1425,338 +1330,223 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
                 fsnr = fsnr_prev;
             }
         }
-        if (failed_alloc >= 0) snroffset = ((failed_alloc - 15) << 4) << 2;
         if (P.tap_snr && lane == 0) { P.tap_snr[fidx * 2] = csnr; P.tap_snr[fidx * 2 + 1] = fsnr; }
         if (P.tap_strat && lane < 36) {
             const int b = lane / 6, ch = lane - 6 * b;
             if (ch < nch) P.tap_strat[(fidx * 6 + b) * nch + ch] = L.strat[b][ch];
         }
-        if (PART == 1) {                    // the packer of this frame is another wavefront
-            if (lane == 0) { P.snr[fidx * 2] = csnr; P.snr[fidx * 2 + 1] = fsnr | (failed_alloc >= 0 ? 0x100 | (failed_alloc << 9) : 0); }
-            continue;
-        }
-
+        // the packer of this frame is another wavefront (enc_packf_kernel) or workgroup (enc_packb_kernel)
+        if (lane == 0) { P.snr[fidx * 2] = csnr; P.snr[fidx * 2 + 1] = fsnr | (failed_alloc >= 0 ? 0x100 | (failed_alloc << 9) : 0); }
         PK_LAP(0);
-        // ---- header (:1113-1147) ----
-        // Side information is wave-uniform: its fields collect in a 64-bit accumulator that stays in scalar registers and
-        // reach the LDS frame up to 64 bits at a time (one lane, two put_bits): `flush` empties it before the lanes write at
-        // `pos` themselves (exponent groups, mantissas) and wherever the next stretch of fields could overflow it - the block's
-        // first stretch is 54 bits at most, the one after the exponents 63 (block 0 of six channels).
-        uint32_t pos = 0;                   // first bit not yet in the frame
-        uint64_t acc = 0;
-        int nacc = 0;                       // pending bits, the low `nacc` of acc
-        auto put = [&](int n, uint32_t v) { acc = (acc << n) | v; nacc += n; };       // (no test per field: at most 64 bits between two flushes)
-        auto flush = [&]() {
-            if (nacc > 32) {
-                if (lane == 0) put_bits(fr, P.frw, pos, nacc - 32, (uint32_t)(acc >> 32) & (0xffffffffu >> (64 - nacc)));
-                pos += nacc - 32;
-                nacc = 32;
-            }
-            if (nacc > 0) {
-                if (lane == 0) put_bits(fr, P.frw, pos, nacc, (uint32_t)acc & (0xffffffffu >> (32 - nacc)));
-                pos += nacc;
-                nacc = 0;
-            }
-        };
-        auto uni = [&](int v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); };
-        put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
-        flush();
-        if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
-        if (P.acmod & 4) put(2, 1);
-        if (P.acmod == 2) put(2, 0);
-        put(1, P.lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
-
-        // ---- audio blocks (:1194-1502) ----
-        for (int b = 0; b < 6; b++) {
-            // this block's encoded exponents, one dword (four bins) per lane and channel, all rows in flight together: the
-            // mantissa passes use them from registers, the exponent groups of a channel through L.erow
-            uint32_t ew[6];
-#pragma unroll
-            for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane) : 0u;
-            if (PART == 2) {                            // this block's mask rows (25 dwords per channel), in flight during the side information
-                const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + (fidx * 6 + b) * nch * 50);
-                uint32_t mv[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) mv[j] = lane + 64 * j < nch * 25 ? gm[lane + 64 * j] : 0u;
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    if (lane + 64 * j < nch * 25) reinterpret_cast<uint32_t *>(&L.mask[0][0])[lane + 64 * j] = mv[j];
-            }
-            flush();
-            for (int ch = 0; ch < nfbw; ch++) put(1, 0);
-            for (int ch = 0; ch < nfbw; ch++) put(1, 1);
-            put(1, 0);
-            if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
-            if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
-            for (int ch = 0; ch < nfbw; ch++) put(2, uni(L.strat[b][ch]));
-            if (P.lfe) put(1, uni(L.strat[b][nch - 1]));
-            for (int ch = 0; ch < nfbw; ch++) if (uni(L.strat[b][ch]) != 0) put(6, P.chbwcod);
-            // exponents: lanes over groups
-            for (int ch = 0; ch < nch; ch++) {
-                const int stg = (int)uni(L.strat[b][ch]);
-                if (stg == 0) continue;
-                const bool is_lfe = P.lfe && ch == nch - 1;
-                const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
-                const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
-                const uint8_t *e = &L.erow[0];
-                {
-                    uint32_t row = 0;
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; c2++) row = c2 == ch ? ew[c2] : row;      // (no indexing of the register array)
-                    WAVE_SYNC();                                            // the previous channel's groups have read the row
-                    *reinterpret_cast<uint32_t *>(&L.erow[4 * lane]) = row;
-                    WAVE_SYNC();
-                }
-                put(4, uni(e[0]));
-                flush();
-                for (int g = lane; g < ng; g += 64) {
-                    const int k0 = 1 + 3 * g * gs;
-                    const int prev = g ? e[k0 - gs] : e[0];
-                    const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
-                    put_bits(fr, P.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
-                }
-                pos += 7 * ng;
-                if (!is_lfe) put(2, 0);
-            }
-            if (b == 0) flush();
-            put(1, b == 0);
-            if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
-            put(1, b == 0);
-            if (b == 0) {
-                put(6, csnr);
-                for (int ch = 0; ch < nch; ch++) { put(4, fsnr); put(3, fgaincod); }
-            }
-            put(1, 0);
-            put(1, 0);
-            flush();
-            PK_LAP(1);
-
-            // ---- mantissas (:1334-1502): one pass per channel, four consecutive coefficients per lane, branch-free.
-            //      A lane's counts of 3/5/11-level mantissas travel as one word of 10-bit fields through one wavefront
-            //      scan (ranks -> who opens a grouped code), its bits through a second (offsets).  A grouped code is
-            //      assembled in L.gtab (rings of 128 / 128 / 256 slots per kind: a pass opens at most 86 / 86 / 128 codes
-            //      and one older code per kind can be incomplete): the opener stores offset and its weighted value, later
-            //      members add theirs, the last member writes the code out.  Lanes with nothing to store or add use the
-            //      sink slot / a zero value instead of a branch. ----
-            {
-                const int32_t *mdb = md + (size_t)b * nch * 256;
-                // The reference quantises a whole block before it writes it, and does not write a grouped code whose
-                // (out-of-contract, garbage) 16-bit value equals 128: everything after it then sits 5 or 7 bits earlier.
-                // First attempt: nominal offsets; such codes are recorded, not written.  If there were any (practically
-                // never), the block's mantissa bits are erased and packed again with those fields left out.
-                const uint32_t pos_m = pos;
-                const uint32_t marker = (uint32_t)P.marker;
-                int dropped_known = 0;
-                if (lane == 0) L.ncoll = 0;
-#pragma unroll 1
-              for (int attempt = 0; attempt < 2; attempt++) {
-                int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
-                // per kind (10-bit fields at 0 / 10 / 20): (codes opened so far mod the kind's ring) x members per code + members of the
-                // open code = the block's count mod 384 / 384 / 512.  A pass's ranks start there, so rank / members IS the ring slot.
-                uint32_t phase = 0;
-                int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
-                uint32_t *const sink = &L.gtab[512 + 2 * lane];
-                // The LFE's seven coefficients ride in the LAST full-bandwidth channel's pass: that channel's 223 bins fill
-                // lanes 0..55, lane 56 + k takes LFE bin k in its first slot - lane order is bitstream order (the LFE follows
-                // the last channel, :1334-1502), so ranks, offsets and grouped codes come out as from a pass of its own, which
-                // would cost as much as a full channel's.
-                const bool lfe_rides = P.lfe && nch >= 2 && nbc <= 224;
-                const int npass = lfe_rides ? nch - 1 : nch;
-                const int lk = lane - 56;                                   // the LFE bin of this lane in the merged pass
-                int lfe_c = 0;
-                if (lfe_rides && lk >= 0 && lk < 7) lfe_c = mdb[(nch - 1) * 256 + lk];
-#pragma unroll 1
-                for (int ch = 0; ch < npass; ch++) {
-                    int4 c4 = nx_c;
-                    uint32_t e4 = 0;
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; c2++) e4 = c2 == ch ? ew[c2] : e4;
-                    {
-                        const int nc = ch + 1 < npass ? ch + 1 : ch;        // the next channel's coefficients are in flight meanwhile
-                        nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
-                    }
-                    const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
-                    const bool lfe_lane = merged && lk >= 0;
-                    const int mrow0 = PART == 2 ? 0 : b * nch;              // (PART 2 holds the block's rows only)
-                    const int16_t *Mr = &L.mask[mrow0 + ch][0];
-                    int shv = (int)L.shiftv[b * 6 + ch];
-                    uint32_t bands = bandoff;
-                    if (merged) {
-                        uint32_t le = 0;
-#pragma unroll
-                        for (int c2 = 0; c2 < 6; c2++) le = c2 == nch - 1 ? ew[c2] : le;
-                        const uint32_t lexp = ((uint32_t)__shfl((int)le, lk >= 0 ? lk >> 2 : 0, 64) >> (8 * (lk & 3))) & 0xffu;
-                        e4 = lfe_lane ? lexp : e4;
-                        c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
-                        Mr = lfe_lane ? &L.mask[mrow0 + nch - 1][0] : Mr;
-                        shv = lfe_lane ? (int)L.shiftv[b * 6 + nch - 1] : shv;
-                        bands = lfe_lane ? (uint32_t)lk : bands;              // (LFE bins 0..6 are bands 0..6)
-                    }
-                    const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
-                    uint32_t pw[4], cnt_lane = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int xe = (int)((e4 >> (8 * j)) & 0xff), m = Mr[(bands >> (8 * j)) & 0xff];
-                        const bool coded = lfe_lane ? (j == 0 && lk < 7) : (4 * lane + j < ((!lfe_rides && P.lfe && ch == nch - 1) ? 7 : nbc));
-                        const int d4 = coded ? 320 - 16 * xe : -(1 << 20);
-                        pw[j] = L.packlut[lut_index(d4, m, snroffset)];
-                        cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
-                    }
-                    if (P.tap_bap) {
-                        uint8_t *tb = P.tap_bap + ((fidx * 6 + b) * nch + ch) * 256;
-                        const uint32_t four = ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
-                        *reinterpret_cast<uint32_t *>(tb + 4 * lane) = lfe_lane ? 0u : four;
-                        if (merged) {                                       // the LFE's row: bins 0..6 from lanes 56..62, zeros beyond
-                            uint8_t *tl = P.tap_bap + ((fidx * 6 + b) * nch + nch - 1) * 256;
-                            if (lane >= 2) *reinterpret_cast<uint32_t *>(tl + 4 * lane) = 0u;
-                            if (lfe_lane) tl[lk] = (uint8_t)(lk < 7 ? (pw[0] >> 20) & 15u : 0u);
-                        }
-                    }
-                    const uint32_t gin = wave_incl_scan_u32(cnt_lane);
-                    uint32_t run = gin - cnt_lane + phase;                          // ranks inside the pass of the lane's next bin, per kind
-                    uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
-                    uint32_t bits_lane = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
-                        const uint32_t r = (run >> sh) & 1023u;                                    // rank counted from the ring's slot 0 (see `phase`)
-                        run += 1u << sh;
-                        const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
-                        const uint32_t gl = kind < 2 ? by3 : by2;                                  // r / 3 or r / 2 (both computed: a select, not a branch)
-                        const uint32_t per = 3u - (kind >> 1);
-                        const uint32_t idx = 3u * kind + (r - gl * per);                           // (kind, member)
-                        const uint32_t F = __builtin_amdgcn_ubfe(AC3MI_GROUP_FLAGS, 3u * idx, 3u);   // 1 opens, 2 last, 4 member
-                        const uint32_t ring = 128u * kind + (gl & (127u | ((kind & 2u) << 6)));
-                        slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
-                        const uint32_t gbits = (pw[j] >> 7) & 7u;
-                        nb[j] = w + gbits * (F & 1u);
-                        bits_lane += nb[j];
-                        fl[j] = F | (gbits << 4) | (gl << 8);
-                        // quantise (:1150-1190)
-                        const int levels = (int)((pw[j] >> 10) & 15u);
-                        const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
-                        const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
-                        const int q = ((pw[j] >> 14) & 1u) ? vs : va;
-                        const int wgt = (F & 2u) ? 1 : (F & 1u) ? (int)((pw[j] >> 15) & 31u) : levels;
-                        vq[j] = (uint32_t)q & 0xffffu;
-                        vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;     // (only the product's low 16 bits count: a 24-bit multiply, not the quarter-rate 32-bit one)
-                    }
-                    if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t kind = (pw[j] >> 5) & 3u;
-                            const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
-                            const uint32_t key = (kind << 16) | full;
-                            bool dropped = false;
-                            for (int q = 0; q < dropped_known; q++) dropped |= L.coll[q] == key;
-                            if (dropped && (fl[j] & 1u)) { bits_lane -= (fl[j] >> 4) & 7u; nb[j] -= (fl[j] >> 4) & 7u; }
-                        }
-                    }
-                    const uint32_t bin_ = wave_incl_scan_u32(bits_lane);
-                    uint32_t off = pos + bin_ - bits_lane;
-                    uint32_t offs[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { offs[j] = off; off += nb[j]; }
-                    // plain mantissas: quantised values live in 16 bits (qmant[] is unsigned short, :1347); only out-of-contract
-                    // ones are wider than their field
-#pragma unroll
-                    for (int j = 0; j < 4; j++) put_bits_always(fr, P.frw, sink, offs[j], (int)(pw[j] & 31u), vq[j]);
-                    // slot = bit offset | 16-bit code << 16: the code accumulates modulo 2^16 like *qmant_ptr += ...
-#pragma unroll
-                    for (int j = 0; j < 4; j++) L.gtab[(fl[j] & 1u) ? slot[j] : 512u + 2u * (uint32_t)lane] = offs[j] | vw[j];
-                    WAVE_SYNC();
-#pragma unroll
-                    for (int j = 0; j < 4; j++) atomicAdd(&L.gtab[(fl[j] & 4u) ? slot[j] : 512u + 2u * (uint32_t)lane], vw[j]);
-                    WAVE_SYNC();
-                    uint32_t hit = 0;
-                    uint32_t xs[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        xs[j] = L.gtab[(fl[j] & 2u) ? slot[j] : 512u + 2u * (uint32_t)lane];
-                        const uint32_t coll = ((fl[j] >> 1) & 1u) * ((xs[j] >> 16) == marker ? 1u : 0u);
-                        hit |= coll;
-                        put_bits_always(fr, P.frw, sink, xs[j] & 0xffffu, (int)(((fl[j] >> 4) & 7u) * ((fl[j] >> 1) & 1u) * (1u - coll)), xs[j] >> 16);
-                    }
-                    if (attempt == 0 && __ballot(hit != 0)) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
-                                const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
-                                const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
-                                const int q = atomicAdd(&L.ncoll, 1);
-                                if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | full;
-                            }
-                    }
-                    WAVE_SYNC();
-                    {
-                        const uint32_t gtot = wave_last(gin);
-                        const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
-                        b3 += t3; b5 += t5; b11 += t11;
-                        phase = (uint32_t)(b3 % 384) | ((uint32_t)(b5 % 384) << 10) | ((uint32_t)(b11 & 511) << 20);
-                    }
-                    pos += wave_last(bin_);
-                }
-                // a trailing group that never got its last member is written as it stands
-                WAVE_SYNC();
-                if (lane == 0) {
-                    auto tail = [&](int kind, int grp, uint32_t x, int gbits) {
-                        if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
-                        else if (attempt == 0) { const int q = L.ncoll++; if (q < 32) L.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
-                    };
-                    if (b3 % 3) tail(0, b3 / 3, L.gtab[(b3 / 3) & 127], 5);
-                    if (b5 % 3) tail(1, b5 / 3, L.gtab[128 + ((b5 / 3) & 127)], 7);
-                    if (b11 & 1) tail(2, b11 >> 1, L.gtab[256 + ((b11 >> 1) & 255)], 7);
-                }
-                WAVE_SYNC();
-                const int ncoll = (int)__builtin_amdgcn_readfirstlane(L.ncoll);
-                if (attempt == 1 || ncoll == 0) break;
-                // erase the block's mantissa bits and pack them again without the dropped fields
-                {
-                    const uint32_t w0 = pos_m >> 5;
-                    if (lane == 0 && (pos_m & 31u)) fr[w0] &= ~(0xffffffffu >> (pos_m & 31u));
-                    for (uint32_t i = w0 + ((pos_m & 31u) ? 1u : 0u) + (uint32_t)lane; i < (uint32_t)P.frw; i += 64) fr[i] = 0u;
-                }
-                pos = pos_m;
-                dropped_known = ncoll < 32 ? ncoll : 32;
-                WAVE_SYNC();
-              }
-            }
-            WAVE_SYNC();
-            PK_LAP(2);
-        }
-
-        // ---- frame end (:1599-1638): bytes past 2*fs are dropped, CRCs stored over whatever is there ----
-        const int fs58 = (fs >> 1) + (fs >> 3);
-        // clear everything from byte 2*fs-2 on? no: the reference only zero-pads when the data is short;
-        // data bits beyond byte 2*fs-2 stay and are then overwritten by crc2 (its own overshoot quirk)
-        uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1_t, 4, lane);
-        crc1 = gf_mul_tab(crc1, P.crc_inv_t);
-        const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2_t, 0, lane);
-        WAVE_SYNC();
-        if (lane == 0) {
-            fr[0] = (fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
-            const int p = 2 * fs - 2;                                                 // even -> inside one dword
-            const int shft = 16 - 8 * (p & 3);
-            fr[p >> 2] = (fr[p >> 2] & ~(0xffffu << shft)) | ((crc2 & 0xffff) << shft);
-        }
-        WAVE_SYNC();
-        uint8_t *dst = P.frames + fidx * P.frame_stride;
-        for (int i = lane; i < (2 * fs + 3) / 4; i += 64) {
-            uint32_t v = __builtin_bswap32(fr[i]);
-            const int rem = 2 * fs - 4 * i;
-            if (rem >= 4) *reinterpret_cast<uint32_t *>(dst + 4 * i) = v;
-            else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
-        }
-        WAVE_SYNC();
-        PK_LAP(3);
     }
-    if ((PART == 0 || PART == 1) && lane == 0) P.csnr_state[sslot] = csnr_prev | (fsnr_prev << 8);
+    if (PART == 1 && lane == 0) P.csnr_state[sslot] = csnr_prev | (fsnr_prev << 8);
     PK_END();
 }
 
 
 // ---------------------------------------------------------------------------------------------
-// enc_packb_kernel: a frame whose SNR offsets are known (P.snr, from enc_pack_kernel<1>) is packed by a workgroup of six
+// enc_packf_kernel: a frame whose SNR offsets are known (P.snr, from enc_search_kernel<1>) is packed by ONE wavefront -
+// the packer of large batches.  Header, side information and exponent groups as wave-uniform fields through a 64-bit
+// scalar accumulator, the mantissas block by block on enc_mant.h, both CRCs, the frame out.
+struct alignas(16) PackfLDS {
+    int16_t mask[6][50];                // this block's masking curves as band terms (mant_band_terms), one row per channel
+    uint32_t packlut[64];               // mant_pack_word per bap table address
+    alignas(16) uint16_t glist[GL_ENTRIES];
+    alignas(4) uint8_t erow[256];       // encoded exponents of the channel whose exponent groups are being packed
+    alignas(4) uint16_t crc_tab[256];
+    // (the frame itself, MSB-first dwords + 256 bytes of headroom for the overshoot quirk, is dynamic LDS: PackParams::frw)
+};
+
+#ifndef ENC_PACK2_LB
+#define ENC_PACK2_LB 4           // 115 VGPRs, no scratch: 1.78 ms per 65 536 frames against 1.84 at 5 per SIMD (96 VGPRs, 72 bytes of scratch)
+#endif
+__global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackParams P)
+{
+    __shared__ PackfLDS L;
+    extern __shared__ uint4 pk_dyn[];
+    uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
+    const int lane = threadIdx.x;
+    const size_t fidx = blockIdx.x;
+    PK_DECL();
+    PK_T0();
+    PK_COUNT(7);
+
+    // (byte loop kept: copying the table as dwords measured 4 % SLOWER in round 3 - code placement, not work)
+    for (int i = lane; i < 256; i += 64) L.crc_tab[i] = P.tab->crc_tab[i];
+    {
+        const int bp = P.tab->baptab[lane];
+        L.packlut[lane] = mant_pack_word(bp, plain_bits(bp));
+    }
+    for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
+    mant_lists_init(L.glist, lane);
+
+    // fixed allocation codes (:861-879)
+    constexpr int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
+    const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
+    const int fs = P.frame_words;
+    const int32_t *md = P.mdct + fidx * 6 * nch * 256;
+    const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
+    // lane 6 b + ch: exponent strategy and exp_samples of channel ch in block b
+    int strat_l = 0, shift_l = 0;
+    if (lane < 36) {
+        const int b = lane / 6, ch = lane - 6 * b;
+        if (ch < nch) { strat_l = (int)P.strat[(fidx * 6 + b) * nch + ch]; shift_l = (int)P.shift[(fidx * 6 + b) * nch + ch]; }
+    }
+    int csnr, fsnr, snroffset;
+    {
+        const int w1 = __builtin_amdgcn_readfirstlane(P.snr[fidx * 2 + 1]);
+        csnr = __builtin_amdgcn_readfirstlane(P.snr[fidx * 2]);
+        fsnr = w1 & 15;
+        snroffset = (((csnr - 15) << 4) + fsnr) << 2;
+        if (w1 & 0x100) snroffset = (((w1 >> 9) - 15) << 4) << 2;       // a frame whose search failed: the last attempt's allocation under the stale header offsets
+    }
+    const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&P.tab->band_of_bin[4 * lane]);     // bands of bins 4*lane..+3
+    WAVE_SYNC();
+    PK_LAP(6);
+
+    // ---- header (:1113-1147) ----
+    // Side information is wave-uniform: its fields collect in a 64-bit accumulator that stays in scalar registers and
+    // reach the LDS frame up to 64 bits at a time (one lane, two put_bits): `flush` empties it before the lanes write at
+    // `pos` themselves (exponent groups, mantissas) and wherever the next stretch of fields could overflow it - the block's
+    // first stretch is 54 bits at most, the one after the exponents 63 (block 0 of six channels).
+    uint32_t pos = 0;                   // first bit not yet in the frame
+    uint64_t acc = 0;
+    int nacc = 0;                       // pending bits, the low `nacc` of acc
+    auto put = [&](int n, uint32_t v) { acc = (acc << n) | v; nacc += n; };       // (no test per field: at most 64 bits between two flushes)
+    auto flush = [&]() {
+        if (nacc > 32) {
+            if (lane == 0) put_bits(fr, P.frw, pos, nacc - 32, (uint32_t)(acc >> 32) & (0xffffffffu >> (64 - nacc)));
+            pos += nacc - 32;
+            nacc = 32;
+        }
+        if (nacc > 0) {
+            if (lane == 0) put_bits(fr, P.frw, pos, nacc, (uint32_t)acc & (0xffffffffu >> (32 - nacc)));
+            pos += nacc;
+            nacc = 0;
+        }
+    };
+    put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+    flush();
+    if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
+    if (P.acmod & 4) put(2, 1);
+    if (P.acmod == 2) put(2, 0);
+    put(1, P.lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
+
+    // ---- audio blocks (:1194-1502) ----
+#pragma unroll 1
+    for (int b = 0; b < 6; b++) {
+        // this block's encoded exponents, one dword (four bins) per lane and channel, all rows in flight together: the
+        // mantissa passes use them from registers, the exponent groups of a channel through L.erow
+        uint32_t ew[6];
+#pragma unroll
+        for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(ex + ((size_t)b * nch + ch) * 256 + 4 * lane) : 0u;
+        {                                           // this block's mask rows (25 dwords per channel), in flight during the side information
+            const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + (fidx * 6 + b) * nch * 50);
+            uint32_t mv[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) mv[j] = lane + 64 * j < nch * 25 ? gm[lane + 64 * j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (lane + 64 * j < nch * 25) reinterpret_cast<uint32_t *>(&L.mask[0][0])[lane + 64 * j] = mant_band_terms(mv[j], snroffset);
+        }
+        auto strat_of = [&](int ch) { return (uint32_t)__builtin_amdgcn_readlane(strat_l, 6 * b + ch); };
+        flush();
+        for (int ch = 0; ch < nfbw; ch++) put(1, 0);
+        for (int ch = 0; ch < nfbw; ch++) put(1, 1);
+        put(1, 0);
+        if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
+        if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
+        for (int ch = 0; ch < nfbw; ch++) put(2, strat_of(ch));
+        if (P.lfe) put(1, strat_of(nch - 1));
+        for (int ch = 0; ch < nfbw; ch++) if (strat_of(ch) != 0) put(6, P.chbwcod);
+        // exponents: lanes over groups
+        for (int ch = 0; ch < nch; ch++) {
+            const int stg = (int)strat_of(ch);
+            if (stg == 0) continue;
+            const bool is_lfe = P.lfe && ch == nch - 1;
+            const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
+            const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
+            const uint8_t *e = &L.erow[0];
+            {
+                uint32_t row = 0;
+#pragma unroll
+                for (int c2 = 0; c2 < 6; c2++) row = c2 == ch ? ew[c2] : row;      // (no indexing of the register array)
+                WAVE_SYNC();                                            // the previous channel's groups have read the row
+                *reinterpret_cast<uint32_t *>(&L.erow[4 * lane]) = row;
+                WAVE_SYNC();
+            }
+            put(4, (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+            flush();
+            for (int g = lane; g < ng; g += 64) {
+                const int k0 = 1 + 3 * g * gs;
+                const int prev = g ? e[k0 - gs] : e[0];
+                const int d0 = e[k0] - prev + 2, d1 = e[k0 + gs] - e[k0] + 2, d2 = e[k0 + 2 * gs] - e[k0 + gs] + 2;
+                put_bits(fr, P.frw, pos + 7 * g, 7, (uint32_t)((d0 * 5 + d1) * 5 + d2));
+            }
+            pos += 7 * ng;
+            if (!is_lfe) put(2, 0);
+        }
+        if (b == 0) flush();
+        put(1, b == 0);
+        if (b == 0) { put(2, sdecaycod); put(2, fdecaycod); put(2, sgaincod); put(2, dbkneecod); put(3, floorcod); }
+        put(1, b == 0);
+        if (b == 0) {
+            put(6, csnr);
+            for (int ch = 0; ch < nch; ch++) { put(4, fsnr); put(3, fgaincod); }
+        }
+        put(1, 0);
+        put(1, 0);
+        flush();
+        PK_LAP(1);
+
+        // ---- mantissas (:1341-1501): enc_mant.h ----
+        {
+            int shv[6];
+#pragma unroll
+            for (int ch = 0; ch < 6; ch++) shv[ch] = __builtin_amdgcn_readlane(shift_l, 6 * b + ch);
+            uint32_t ad[6];
+            int neg;
+            uint32_t em[6];
+            mant_block_addresses(ad, em, neg, ew, shv, L.mask, bandoff, nch, nbc, P.lfe != 0, lane);
+            PK_LAP(8);
+            MantBlock B;
+            B.fr = fr; B.frw = P.frw; B.glist = L.glist; B.packlut = L.packlut;
+            B.mdb = md + (size_t)b * nch * 256;
+            B.tap_bap = P.tap_bap ? P.tap_bap + (fidx * 6 + b) * nch * 256 : nullptr;
+            B.nch = nch; B.nbc = nbc; B.lfe = P.lfe != 0; B.marker = (uint32_t)P.marker;
+            pos = mant_pack_block(B, em, ad, shv, __ballot(neg < 0) != 0, pos, lane);
+        }
+        PK_LAP(2);
+    }
+
+    // ---- frame end (:1599-1638): bytes past 2*fs are dropped, CRCs stored over whatever is there ----
+    const int fs58 = (fs >> 1) + (fs >> 3);
+    // (the reference only zero-pads when the data is short; data bits beyond byte 2*fs-2 stay and are then overwritten by
+    // crc2 - its own overshoot quirk)
+    uint32_t crc1 = region_crc(L, fr, 2 * fs58, 2 * fs58, P.c1, P.pw1_t, 4, lane);
+    crc1 = gf_mul_tab(crc1, P.crc_inv_t);
+    const uint32_t crc2 = region_crc(L, fr, 2 * fs - 2, (fs - fs58) * 2 - 2, P.c2, P.pw2_t, 0, lane);
+    WAVE_SYNC();
+    if (lane == 0) {
+        fr[0] = (fr[0] & 0xffff0000u) | (crc1 & 0xffff);                      // bytes 2,3
+        const int p = 2 * fs - 2;                                                 // even -> inside one dword
+        const int shft = 16 - 8 * (p & 3);
+        fr[p >> 2] = (fr[p >> 2] & ~(0xffffu << shft)) | ((crc2 & 0xffff) << shft);
+    }
+    WAVE_SYNC();
+    uint8_t *dst = P.frames + fidx * P.frame_stride;
+    for (int i = lane; i < (2 * fs + 3) / 4; i += 64) {
+        uint32_t v = __builtin_bswap32(fr[i]);
+        const int rem = 2 * fs - 4 * i;
+        if (rem >= 4) *reinterpret_cast<uint32_t *>(dst + 4 * i) = v;
+        else for (int k = 0; k < rem; k++) dst[4 * i + k] = (uint8_t)(v >> (8 * k));
+    }
+    PK_LAP(3);
+    PK_END();
+}
+
+// ---------------------------------------------------------------------------------------------
+// enc_packb_kernel: a frame whose SNR offsets are known (P.snr, from enc_search_kernel<1>) is packed by a workgroup of six
 // wavefronts, one per AUDIO BLOCK.  Nothing but its first bit ties a block to the blocks before it, and that follows from
 // bit COUNTS: every wavefront first counts its block (side information from the strategies, mantissas from one table look-up
 // per coefficient), the counts meet in LDS, then all six pack at once into the frame they share (fields reach it by LDS
@@ -1766,18 +1556,17 @@ __global__ __launch_bounds__(64, PART == 1 ? ENC_SEARCH_LB : PART == 2 ? ENC_PAC
 // with those fields at width 0 - as enc_pack_kernel does per block.
 
 struct PackbWave {                  // per wavefront = audio block
-    int16_t mask[6][50];            // masking curves of the block's channels, minus the floor
-    uint32_t gtab[640];             // see PackLDS::gtab
+    int16_t mask[6][50];            // masking curves of the block's channels as band terms (mant_band_terms)
+    alignas(16) uint16_t glist[GL_ENTRIES];     // members of the block's grouped codes (enc_mant.h)
     alignas(4) uint8_t erow[256];
-    uint32_t coll[32];
-    int ncoll;
 };
 struct alignas(16) PackbLDS {
     PackbWave w[6];
     uint32_t packlut[64];
     uint16_t crc_tab[256];
     uint8_t band_of_bin[256];
-    uint32_t blk_bits[6];
+    uint32_t blk_bits[6];           // bits of each block: nominal (from the bap codes) ...
+    uint32_t blk_bits2[6];          // ... and as packed (a grouped code equal to the merged-marker takes none)
     uint32_t crc[2];
     int any_coll;
 };
@@ -1808,12 +1597,15 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         L.band_of_bin[i] = P.tab->band_of_bin[i];
         L.crc_tab[i] = P.tab->crc_tab[i];
     }
-    if (tid < 64) L.packlut[tid] = pack_word(P.tab->baptab[tid]);
+    if (tid < 64) { const int bp = P.tab->baptab[tid]; L.packlut[tid] = mant_pack_word(bp, plain_bits(bp)); }
     for (int i = tid; i < P.frw / 4; i += 384) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
     const size_t rowb = (fidx * 6 + b) * nch;
+    uint32_t mrows[3] = {0u, 0u, 0u};                   // the block's masking curves, two bands per dword (to LDS as band terms once the offsets are known)
     {
         const uint32_t *gm = reinterpret_cast<const uint32_t *>(P.emask + rowb * 50);
-        for (int i = lane; i < nch * 25; i += 64) reinterpret_cast<uint32_t *>(&W.mask[0][0])[i] = gm[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (lane + 64 * j < nch * 25) mrows[j] = gm[lane + 64 * j];
     }
     // lane = channel: exponent strategy and exp_samples of the block's channels
     const int strat_l = lane < nch ? (int)P.strat[rowb + lane] : 0;
@@ -1821,7 +1613,6 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
     uint32_t ew[6];                                     // the block's encoded exponents, four bins per lane and channel
 #pragma unroll
     for (int ch = 0; ch < 6; ch++) ew[ch] = ch < nch ? *reinterpret_cast<const uint32_t *>(P.eexp + (rowb + ch) * 256 + 4 * lane) : 0u;
-    const int32_t *mdb = P.mdct + rowb * 256;
     int csnr, fsnr, snroffset;
     {
         const int w1 = P.snr[fidx * 2 + 1];
@@ -1830,8 +1621,11 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         snroffset = (((csnr - 15) << 4) + fsnr) << 2;
         if (w1 & 0x100) snroffset = (((w1 >> 9) - 15) << 4) << 2;      // a frame whose search failed: see enc_pack_kernel
     }
-    if (lane == 0) W.ncoll = 0;
     if (tid == 0) L.any_coll = 0;
+    mant_lists_init(W.glist, lane);
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (lane + 64 * j < nch * 25) reinterpret_cast<uint32_t *>(&W.mask[0][0])[lane + 64 * j] = mant_band_terms(mrows[j], snroffset);
     const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&P.tab->band_of_bin[4 * lane]);
     __syncthreads();
 
@@ -1850,28 +1644,19 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         side_bits += 4 + 7 * (((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs)) + (is_lfe ? 0 : 8);      // (fbw: chbwcod 6 + gainrng 2)
     }
 
-    // the addresses of the block's coefficients into the bap table (:393-420), four per lane and channel: 6 bits each
-    uint32_t ad[6];
+    // the addresses of the block's coefficients into the bap table (:393-420), four per lane and channel
+    uint32_t ad[6], em[6];
+    int shv[6], neg;
 #pragma unroll
-    for (int ch = 0; ch < 6; ch++) {
-        ad[ch] = 0;
-        if (ch < nch) {
-            const int n = (P.lfe && ch == nch - 1) ? 7 : nbc;
-            const int16_t *Mr = &W.mask[ch][0];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int xe = (int)((ew[ch] >> (8 * j)) & 0xff), m = Mr[(bandoff >> (8 * j)) & 0xff];
-                const int d4 = 4 * lane + j < n ? 320 - 16 * xe : -(1 << 20);
-                ad[ch] |= (uint32_t)lut_index(d4, m, snroffset) << (8 * j);
-            }
-        }
-    }
+    for (int ch = 0; ch < 6; ch++) shv[ch] = __builtin_amdgcn_readlane(shift_l, ch);
+    mant_block_addresses(ad, em, neg, ew, shv, W.mask, bandoff, nch, nbc, P.lfe != 0, lane);
+    const bool garbage = __ballot(neg < 0) != 0;
 
-    int dropped_known = 0;
 #pragma unroll 1
     for (int attempt = 0; attempt < 2; attempt++) {
-        // ---- this block's bit count -> where it starts ----
-        {
+        // ---- this block's bit count -> where it starts (second attempt: the counts as packed) ----
+        int mant_bits = 0;
+        if (attempt == 0) {
             uint32_t cnt = 0, plain = 0;            // kinds as 10-bit fields (<= 24 per lane), plain bits
 #pragma unroll
             for (int ch = 0; ch < 6; ch++) {
@@ -1886,13 +1671,12 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
             const uint32_t s1 = wave_sum_u32((cnt & 1023u) | (((cnt >> 10) & 1023u) << 16));
             const uint32_t s2 = wave_sum_u32(((cnt >> 20) & 1023u) | (plain << 16));
             const int n1 = s1 & 0xffff, n2 = s1 >> 16, n4 = s2 & 0xffff;
-            int bits = side_bits + (int)(s2 >> 16) + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
-            for (int q = 0; q < dropped_known; q++) bits -= (W.coll[q] >> 16) == 0 ? 5 : 7;
-            if (lane == 0) L.blk_bits[b] = (uint32_t)bits;
+            mant_bits = (int)(s2 >> 16) + 5 * ((n1 + 2) / 3) + 7 * ((n2 + 2) / 3) + 7 * ((n4 + 1) / 2);
+            if (lane == 0) L.blk_bits[b] = (uint32_t)(side_bits + mant_bits);
         }
         __syncthreads();
         uint32_t pos = (uint32_t)hdr_bits;
-        for (int q = 0; q < b; q++) pos += L.blk_bits[q];
+        for (int q = 0; q < b; q++) pos += attempt == 0 ? L.blk_bits[q] : L.blk_bits2[q];
 
         // ---- side information (wave-uniform fields through a 64-bit accumulator, see enc_pack_kernel) ----
         uint64_t acc = 0;
@@ -1969,164 +1753,26 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
         put(1, 0);
         flush();
 
-        // ---- mantissas (:1334-1502): as in enc_pack_kernel, one pass per channel, four coefficients per lane ----
+        // ---- mantissas (:1341-1501): enc_mant.h ----
         {
-            const uint32_t marker = (uint32_t)P.marker;
-            int b3 = 0, b5 = 0, b11 = 0;        // 3/5/11-level mantissas of the block so far
-            uint32_t phase = 0;                 // see enc_pack_kernel
-            int4 nx_c = *reinterpret_cast<const int4 *>(mdb + 4 * lane);
-            uint32_t *const sink = &W.gtab[512 + 2 * lane];
-            // the LFE's seven coefficients ride in the last full-bandwidth channel's pass (lanes 56..62): see enc_pack_kernel
-            const bool lfe_rides = P.lfe && nch >= 2 && nbc <= 224;
-            const int npass = lfe_rides ? nch - 1 : nch;
-            const int lk = lane - 56;
-            int lfe_c = 0;
-            if (lfe_rides && lk >= 0 && lk < 7) lfe_c = mdb[(nch - 1) * 256 + lk];
-#pragma unroll 1
-            for (int ch = 0; ch < npass; ch++) {
-                int4 c4 = nx_c;
-                uint32_t e4 = 0, a4 = 0;
-#pragma unroll
-                for (int c2 = 0; c2 < 6; c2++) { e4 = c2 == ch ? ew[c2] : e4; a4 = c2 == ch ? ad[c2] : a4; }
-                {
-                    const int nc = ch + 1 < npass ? ch + 1 : ch;        // the next channel's coefficients are in flight meanwhile
-                    nx_c = *reinterpret_cast<const int4 *>(mdb + nc * 256 + 4 * lane);
-                }
-                const bool merged = lfe_rides && ch == npass - 1;       // wave-uniform
-                const bool lfe_lane = merged && lk >= 0;
-                int shv = __builtin_amdgcn_readlane(shift_l, ch);
-                if (merged) {
-                    uint32_t le = 0, la = 0;
-#pragma unroll
-                    for (int c2 = 0; c2 < 6; c2++) { le = c2 == nch - 1 ? ew[c2] : le; la = c2 == nch - 1 ? ad[c2] : la; }
-                    const int srcl = lk >= 0 ? lk >> 2 : 0;
-                    const uint32_t lexp = ((uint32_t)__shfl((int)le, srcl, 64) >> (8 * (lk & 3))) & 0xffu;
-                    const uint32_t ladr = ((uint32_t)__shfl((int)la, srcl, 64) >> (8 * (lk & 3))) & 63u;
-                    e4 = lfe_lane ? lexp : e4;
-                    a4 = lfe_lane ? (lk < 7 ? ladr : 0u) : a4;              // (address 0: bap 0, no bits - the lane's other three slots)
-                    c4 = lfe_lane ? make_int4(lfe_c, 0, 0, 0) : c4;
-                    shv = lfe_lane ? __builtin_amdgcn_readlane(shift_l, nch - 1) : shv;
-                }
-                const int cj[4] = {c4.x, c4.y, c4.z, c4.w};
-                uint32_t pw[4], cnt_lane = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    pw[j] = L.packlut[(a4 >> (8 * j)) & 63u];
-                    cnt_lane += 1u << (pw[j] >> 24);                    // (a bin that is not grouped counts in bits 30-31: ignored)
-                }
-                if (P.tap_bap) {
-                    uint8_t *tb = P.tap_bap + (rowb + ch) * 256;
-                    const uint32_t four = ((pw[0] >> 20) & 15u) | (((pw[1] >> 20) & 15u) << 8) | (((pw[2] >> 20) & 15u) << 16) | (((pw[3] >> 20) & 15u) << 24);
-                    *reinterpret_cast<uint32_t *>(tb + 4 * lane) = lfe_lane ? 0u : four;
-                    if (merged) {
-                        uint8_t *tl = P.tap_bap + (rowb + nch - 1) * 256;
-                        if (lane >= 2) *reinterpret_cast<uint32_t *>(tl + 4 * lane) = 0u;
-                        if (lfe_lane) tl[lk] = (uint8_t)(lk < 7 ? (pw[0] >> 20) & 15u : 0u);
-                    }
-                }
-                const uint32_t gin = wave_incl_scan_u32(cnt_lane);
-                uint32_t run = gin - cnt_lane + phase;
-                uint32_t vq[4], vw[4], nb[4], slot[4], fl[4];           // fl: 1 opens, 2 last, 4 member | bits of the code << 4
-                uint32_t bits_lane = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t w = pw[j] & 31u, kind = (pw[j] >> 5) & 3u, sh = pw[j] >> 24;
-                    const uint32_t r = (run >> sh) & 1023u;
-                    run += 1u << sh;
-                    const uint32_t by3 = (r * 0xaaabu) >> 17, by2 = r >> 1;
-                    const uint32_t gl = kind < 2 ? by3 : by2;
-                    const uint32_t per = 3u - (kind >> 1);
-                    const uint32_t idx = 3u * kind + (r - gl * per);
-                    const uint32_t F = __builtin_amdgcn_ubfe(AC3MI_GROUP_FLAGS, 3u * idx, 3u);
-                    const uint32_t ring = 128u * kind + (gl & (127u | ((kind & 2u) << 6)));
-                    slot[j] = kind == 3 ? 512u + 2u * (uint32_t)lane : ring;
-                    const uint32_t gbits = (pw[j] >> 7) & 7u;
-                    nb[j] = w + gbits * (F & 1u);
-                    bits_lane += nb[j];
-                    fl[j] = F | (gbits << 4) | (gl << 8);
-                    const int levels = (int)((pw[j] >> 10) & 15u);
-                    const int e = (int)((e4 >> (8 * j)) & 0xff) - shv;
-                    const int vs = quant_sym(cj[j], e, levels), va = quant_asym(cj[j], e, w ? (int)w : 1);
-                    const int q = ((pw[j] >> 14) & 1u) ? vs : va;
-                    const int wgt = (F & 2u) ? 1 : (F & 1u) ? (int)((pw[j] >> 15) & 31u) : levels;
-                    vq[j] = (uint32_t)q & 0xffffu;
-                    vw[j] = __umul24((uint32_t)q & 0xffffu, (uint32_t)wgt) << 16;
-                }
-                if (dropped_known) {                                 // second attempt only: the recorded openers take no bits
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t kind = (pw[j] >> 5) & 3u;
-                        const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
-                        const uint32_t key = (kind << 16) | full;
-                        bool dropped = false;
-                        for (int q = 0; q < dropped_known; q++) dropped |= W.coll[q] == key;
-                        if (dropped && (fl[j] & 1u)) { bits_lane -= (fl[j] >> 4) & 7u; nb[j] -= (fl[j] >> 4) & 7u; }
-                    }
-                }
-                const uint32_t bin_ = wave_incl_scan_u32(bits_lane);
-                uint32_t off = pos + bin_ - bits_lane;
-                uint32_t offs[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { offs[j] = off; off += nb[j]; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) put_bits_always(fr, P.frw, sink, offs[j], (int)(pw[j] & 31u), vq[j]);
-#pragma unroll
-                for (int j = 0; j < 4; j++) W.gtab[(fl[j] & 1u) ? slot[j] : 512u + 2u * (uint32_t)lane] = offs[j] | vw[j];
-                WAVE_SYNC();
-#pragma unroll
-                for (int j = 0; j < 4; j++) atomicAdd(&W.gtab[(fl[j] & 4u) ? slot[j] : 512u + 2u * (uint32_t)lane], vw[j]);
-                WAVE_SYNC();
-                uint32_t hit = 0;
-                uint32_t xs[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    xs[j] = W.gtab[(fl[j] & 2u) ? slot[j] : 512u + 2u * (uint32_t)lane];
-                    const uint32_t coll = ((fl[j] >> 1) & 1u) * ((xs[j] >> 16) == marker ? 1u : 0u);
-                    hit |= coll;
-                    put_bits_always(fr, P.frw, sink, xs[j] & 0xffffu, (int)(((fl[j] >> 4) & 7u) * ((fl[j] >> 1) & 1u) * (1u - coll)), xs[j] >> 16);
-                }
-                if (attempt == 0 && __ballot(hit != 0)) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if ((fl[j] & 2u) && (xs[j] >> 16) == marker) {
-                            const int kind = slot[j] >= 256 ? 2 : (int)(slot[j] >> 7);
-                            const uint32_t full = (uint32_t)(kind == 0 ? (b3 / 3) & ~127 : kind == 1 ? (b5 / 3) & ~127 : (b11 >> 1) & ~255) + (fl[j] >> 8)      /* (fl >> 8 counts from the ring's slot 0) */;
-                            const int q = atomicAdd(&W.ncoll, 1);
-                            if (q < 32) W.coll[q] = ((uint32_t)kind << 16) | full;
-                        }
-                }
-                WAVE_SYNC();
-                {
-                    const uint32_t gtot = wave_last(gin);
-                    const int t3 = (int)(gtot & 1023u), t5 = (int)((gtot >> 10) & 1023u), t11 = (int)((gtot >> 20) & 1023u);
-                    b3 += t3; b5 += t5; b11 += t11;
-                    phase = (uint32_t)(b3 % 384) | ((uint32_t)(b5 % 384) << 10) | ((uint32_t)(b11 & 511) << 20);
-                }
-                pos += wave_last(bin_);
-            }
-            // a trailing group that never got its last member is written as it stands
-            WAVE_SYNC();
-            if (lane == 0) {
-                auto tail = [&](int kind, int grp, uint32_t x, int gbits) {
-                    if ((x >> 16) != marker) put_bits(fr, P.frw, x & 0xffffu, gbits, x >> 16);
-                    else if (attempt == 0) { const int q = W.ncoll++; if (q < 32) W.coll[q] = ((uint32_t)kind << 16) | (uint32_t)grp; }
-                };
-                if (b3 % 3) tail(0, b3 / 3, W.gtab[(b3 / 3) & 127], 5);
-                if (b5 % 3) tail(1, b5 / 3, W.gtab[128 + ((b5 / 3) & 127)], 7);
-                if (b11 & 1) tail(2, b11 >> 1, W.gtab[256 + ((b11 >> 1) & 255)], 7);
-                if (attempt == 0 && W.ncoll) L.any_coll = 1;
+            MantBlock B;
+            B.fr = fr; B.frw = P.frw; B.glist = W.glist; B.packlut = L.packlut;
+            B.mdb = P.mdct + rowb * 256;
+            B.tap_bap = P.tap_bap ? P.tap_bap + rowb * 256 : nullptr;
+            B.nch = nch; B.nbc = nbc; B.lfe = P.lfe != 0; B.marker = (uint32_t)P.marker;
+            const uint32_t pos_m = pos;
+            pos = mant_pack_block(B, em, ad, shv, garbage, pos, lane);
+            // a grouped code that equals the merged-marker (:1466-1480) takes no bits: the block is shorter than its bap codes say,
+            // i.e. every later block moves - the workgroup then packs the frame once more from the counts as packed
+            if (attempt == 0 && lane == 0) {
+                L.blk_bits2[b] = (uint32_t)side_bits + (pos - pos_m);
+                if ((int)(pos - pos_m) != mant_bits) L.any_coll = 1;
             }
         }
         __syncthreads();
         if (attempt == 1 || !L.any_coll) break;
-        // a dropped field moves everything behind it: the frame is erased and every block packed again with its recorded
-        // fields at width 0
         __syncthreads();
         for (int i = tid; i < P.frw / 4; i += 384) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
-        {
-            const int nc = __builtin_amdgcn_readfirstlane(W.ncoll);
-            dropped_known = nc < 32 ? nc : 32;
-        }
         __syncthreads();
     }
 
@@ -2160,8 +1806,8 @@ __global__ __launch_bounds__(384, ENC_PACKB_LB) void enc_packb_kernel(const Pack
 #ifdef PACK_STAMPS
 extern "C" __attribute__((visibility("default"))) int ac3mi_debug_pack_cycles(unsigned long long *out8, int reset)
 {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pack_cycles), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pack_cycles), z, sizeof z) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pack_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pack_cycles), z, sizeof z) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -2273,7 +1919,7 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     P.frw = ((2 * fs + ENC_FR_HEADROOM + 15) / 16) * 4;
     P.marker = getenv("AC3MI_ENC_MARKER") ? atoi(getenv("AC3MI_ENC_MARKER")) : 128;      // test aid (read per launch), see PackParams::marker
     static const int lds_pad = getenv("AC3MI_ENC_LDS_PAD") ? atoi(getenv("AC3MI_ENC_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
-    const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;       // the searching-only parts (1, 3) never touch it
+    const size_t fr_lds = (size_t)P.frw * 4 + lds_pad;
     // The SNR-offset searches run one wavefront per stream (PART 1; for few long streams behind PART 3's frame-parallel
     // tabulation), then every frame is packed by a workgroup of six wavefronts, one per audio block (enc_packb_kernel).
     // Measured per call on one-frame streams, cold (profiles/encode_cold.py, end of round 3): 64 frames 0.107 against 0.162 ms
@@ -2285,19 +1931,13 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     const unsigned nfr = (unsigned)E.n_streams * (unsigned)E.frames_per_stream;
     const bool long_streams = E.frames_per_stream > 1 && E.n_streams < 5120;
     const bool packb = E.pack_mode == 2 || (E.pack_mode == 0 && nfr <= 1024);
-    // Large batches of one-frame streams: search kernel (PART 1) + one wavefront per frame packs (PART 2) instead of the
-    // one-kernel PART 0, whose register budget holds neither half comfortably (128 VGPRs + scratch against 98 and 97).
-    // AC3MI_ENC_BIG_SPLIT=0: PART 0 (A/B runs).
-    static const int big_split = getenv("AC3MI_ENC_BIG_SPLIT") ? atoi(getenv("AC3MI_ENC_BIG_SPLIT")) : 1;
-    if (E.ws_snr && (packb || long_streams || big_split)) {
-        P.memo = long_streams && E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
-        if (P.memo) hipLaunchKernelGGL(enc_pack_kernel<3>, dim3(nfr), dim3(64), 16, stream, P);
-        hipLaunchKernelGGL(enc_pack_kernel<1>, dim3(E.n_streams), dim3(64), 16, stream, P);
-        if (packb) hipLaunchKernelGGL(enc_packb_kernel, dim3(nfr), dim3(384), fr_lds, stream, P);
-        else hipLaunchKernelGGL(enc_pack_kernel<2>, dim3(nfr), dim3(64), fr_lds, stream, P);
-    } else {
-        hipLaunchKernelGGL(enc_pack_kernel<0>, dim3(E.n_streams), dim3(64), fr_lds, stream, P);
-    }
+    // Always two steps: the searches (enc_search_kernel), then the packers - one wavefront per frame (enc_packf_kernel) beyond
+    // 1 024 frames.  (Rounds 1-3 also had a one-kernel packer per stream; it held neither half's registers comfortably.)
+    P.memo = long_streams && E.n_streams < 2048 ? E.ws_memo : nullptr;      // worth its cost only when the per-stream replay is the long pole
+    if (P.memo) hipLaunchKernelGGL(enc_search_kernel<3>, dim3(nfr), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL(enc_search_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
+    if (packb) hipLaunchKernelGGL(enc_packb_kernel, dim3(nfr), dim3(384), fr_lds, stream, P);
+    else hipLaunchKernelGGL(enc_packf_kernel, dim3(nfr), dim3(64), fr_lds, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame

@@ -28,17 +28,19 @@ csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
 frames = torch.zeros((S, 1, enc.frame_bytes()), dtype=torch.uint8, device=dev)
 lib = eng.lib
 lib.ac3mi_debug_pack_cycles.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 for it in range(3):
     eng.encode_batch(enc, pcm, (0, 2, 1, 4, 5, 3), last, csnr, out=frames)
     torch.cuda.synchronize()
     assert lib.ac3mi_debug_pack_cycles(out, 1) == 0
     n = max(out[5], 1)
-    names = ("set-up + search", "header, side info, exponents", "mantissas", "CRC + store")
-    tot = sum(out[i] for i in range(4))
-    print("pass %d: %d frames, %.2f searches/frame" % (it, out[5], out[4] / n))
+    names = ("search kernel: set-up + search", "packer: header, side info, exponents", "packer: mantissas (whole)", "packer: CRC + store", None, None, "packer: set-up", None,
+             "  mantissas: bap addresses", "  mantissas: stage 1", "  mantissas: stage 2")
+    tot = sum(out[i] for i in (0, 1, 2, 3, 6))
+    print("pass %d: %d + %d frames, %.2f searches/frame" % (it, out[5], out[7], out[4] / n))
     for i, nm in enumerate(names):
-        print("   %-30s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
+        if nm:
+            print("   %-40s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
 # second-generation content (the transcode's encoder half): the frames above decoded to s16, encoded from fresh state
 dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=enc.frame_bytes())
 delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
@@ -52,7 +54,8 @@ eng.encode_batch(enc, s16.reshape(S, 1, 1536, 6), (0, 2, 1, 4, 5, 3), last, csnr
 torch.cuda.synchronize()
 assert lib.ac3mi_debug_pack_cycles(out, 1) == 0
 n = max(out[5], 1)
-tot = sum(out[i] for i in range(4))
+tot = sum(out[i] for i in (0, 1, 2, 3, 6))
 print("decoded content, cold: %d frame visits, %.2f searches/frame visit" % (out[5], out[4] / n))
 for i, nm in enumerate(names):
-    print("   %-30s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
+    if nm:
+        print("   %-40s %9.0f ticks/frame  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / max(tot, 1)))
