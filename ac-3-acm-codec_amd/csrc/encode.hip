@@ -1360,6 +1360,9 @@ struct alignas(16) PackfLDS {
 #ifndef ENC_PACK2_LB
 #define ENC_PACK2_LB 4           // 115 VGPRs, no scratch: 1.78 ms per 65 536 frames against 1.84 at 5 per SIMD (96 VGPRs, 72 bytes of scratch)
 #endif
+// FIXED51: the 5.1 configuration (five full-bandwidth channels + LFE, acmod 7) as compile-time constants - the shape large batches
+// have; its five mantissa passes, the merged LFE lanes and the side information's field list then need no tests
+template <bool FIXED51>
 __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackParams P)
 {
     __shared__ PackfLDS L;
@@ -1382,7 +1385,9 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
 
     // fixed allocation codes (:861-879)
     constexpr int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
-    const int nch = P.nch, nfbw = P.nfbw, nbc = P.nbc;
+    const int nch = FIXED51 ? 6 : P.nch, nfbw = FIXED51 ? 5 : P.nfbw, nbc = FIXED51 ? 223 : P.nbc;
+    const int acmod = FIXED51 ? 7 : P.acmod;
+    const bool lfe = FIXED51 ? true : P.lfe != 0;
     const int fs = P.frame_words;
     const int32_t *md = P.mdct + fidx * 6 * nch * 256;
     const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
@@ -1425,12 +1430,12 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
             nacc = 0;
         }
     };
-    put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, P.acmod);
+    put(16, 0x0b77); put(16, 0); put(2, P.fscod); put(6, P.frmsizecod); put(5, P.bsid); put(3, 0); put(3, acmod);
     flush();
-    if ((P.acmod & 1) && P.acmod != 1) put(2, 1);
-    if (P.acmod & 4) put(2, 1);
-    if (P.acmod == 2) put(2, 0);
-    put(1, P.lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
+    if ((acmod & 1) && acmod != 1) put(2, 1);
+    if (acmod & 4) put(2, 1);
+    if (acmod == 2) put(2, 0);
+    put(1, lfe); put(5, 31); put(3, 0); put(1, 0); put(1, 1); put(3, 0);
 
     // ---- audio blocks (:1194-1502) ----
 #pragma unroll 1
@@ -1455,15 +1460,15 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
         for (int ch = 0; ch < nfbw; ch++) put(1, 1);
         put(1, 0);
         if (b == 0) { put(1, 1); put(1, 0); } else put(1, 0);
-        if (P.acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
+        if (acmod == 2) { if (b == 0) { put(1, 1); put(4, 0); } else put(1, 0); }
         for (int ch = 0; ch < nfbw; ch++) put(2, strat_of(ch));
-        if (P.lfe) put(1, strat_of(nch - 1));
+        if (lfe) put(1, strat_of(nch - 1));
         for (int ch = 0; ch < nfbw; ch++) if (strat_of(ch) != 0) put(6, P.chbwcod);
         // exponents: lanes over groups
         for (int ch = 0; ch < nch; ch++) {
             const int stg = (int)strat_of(ch);
             if (stg == 0) continue;
-            const bool is_lfe = P.lfe && ch == nch - 1;
+            const bool is_lfe = lfe && ch == nch - 1;
             const int gs = stg == 1 ? 1 : stg == 2 ? 2 : 4;
             const int ng = ((is_lfe ? 7 : nbc) + gs * 3 - 4) / (3 * gs);
             const uint8_t *e = &L.erow[0];
@@ -1507,13 +1512,13 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
             uint32_t ad[6];
             int neg;
             uint32_t em[6];
-            mant_block_addresses(ad, em, neg, ew, shv, L.mask, bandoff, nch, nbc, P.lfe != 0, lane);
+            mant_block_addresses(ad, em, neg, ew, shv, L.mask, bandoff, nch, nbc, lfe, lane);
             PK_LAP(8);
             MantBlock B;
             B.fr = fr; B.frw = P.frw; B.glist = L.glist; B.packlut = L.packlut;
             B.mdb = md + (size_t)b * nch * 256;
             B.tap_bap = P.tap_bap ? P.tap_bap + (fidx * 6 + b) * nch * 256 : nullptr;
-            B.nch = nch; B.nbc = nbc; B.lfe = P.lfe != 0; B.marker = (uint32_t)P.marker;
+            B.nch = nch; B.nbc = nbc; B.lfe = lfe; B.marker = (uint32_t)P.marker;
             pos = mant_pack_block(B, em, ad, shv, __ballot(neg < 0) != 0, pos, lane);
         }
         PK_LAP(2);
@@ -1937,7 +1942,8 @@ hipError_t launch_encode(const DeviceTables &tab, const EncodeLaunch &E, hipStre
     if (P.memo) hipLaunchKernelGGL(enc_search_kernel<3>, dim3(nfr), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(enc_search_kernel<1>, dim3(E.n_streams), dim3(64), 0, stream, P);
     if (packb) hipLaunchKernelGGL(enc_packb_kernel, dim3(nfr), dim3(384), fr_lds, stream, P);
-    else hipLaunchKernelGGL(enc_packf_kernel, dim3(nfr), dim3(64), fr_lds, stream, P);
+    else if (c.nch == 6 && c.nfbw == 5 && c.lfe && c.acmod == 7 && P.nbc == 223) hipLaunchKernelGGL(enc_packf_kernel<true>, dim3(nfr), dim3(64), fr_lds, stream, P);
+    else hipLaunchKernelGGL(enc_packf_kernel<false>, dim3(nfr), dim3(64), fr_lds, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the new history: last 256 samples per channel of each stream's final frame
