@@ -756,6 +756,24 @@ static bool use_split(const ac3mi_ctx *ctx)
     return ctx->decode_mode == 0 || ctx->decode_mode >= 4;
 }
 
+// the encoder's workspace for `rows` channel-blocks (6 x channels per frame):
+// mdct | raw exponents | encoded exponents | masking curves | exp_samples | strategies | exponent bits | search results | verdict tables
+struct EncWs { size_t off_eexp, off_emask, off_shift, off_strat, off_ebits, off_snr, off_memo, need; };
+static EncWs enc_ws_layout(size_t rows)
+{
+    EncWs w;
+    const size_t rows_pad = (rows + 255) & ~(size_t)255;
+    w.off_eexp = rows * 256 * 4 + rows * 256;
+    w.off_emask = w.off_eexp + rows * 256;
+    w.off_shift = w.off_emask + ((rows * 100 + 255) & ~(size_t)255);
+    w.off_strat = w.off_shift + rows_pad;
+    w.off_ebits = w.off_strat + rows_pad;
+    w.off_snr = w.off_ebits + rows_pad * 4;
+    w.off_memo = w.off_snr + rows_pad * 2;              // [S][F][2] int32 <= rows / 3 entries
+    w.need = w.off_memo + rows_pad * 6 + 1024;          // [S][F][8] uint32
+    return w;
+}
+
 // workspace of the split front end for nfr frames: descriptors, generator positions, coupling coordinates, row sets
 struct SplitWs { void *desc; uint32_t *fpos; float *cplco; uint8_t *rows; };
 static size_t split_bytes(size_t nfr) { return nfr * (6 * 80 + 16 + 6 * 90 * 4 + 6 * 7 * 512) + 256; }
@@ -808,6 +826,21 @@ static int ensure_draws(ac3mi_ctx *ctx, size_t nfr)
     HIPCHK(ctx, hipMalloc((void **)&ctx->ws_draws, need));
     ctx->ws_draws_bytes = need;
     return AC3MI_OK;
+}
+
+size_t ac3mi_workspace_bytes(const ac3mi_ctx *ctx)
+{
+    if (!ctx) return 0;
+    return ctx->ws_coef_bytes + ctx->ws_blksw_bytes + ctx->ws_enc_bytes + ctx->ws_tc_bytes + ctx->ws_draws_bytes + ctx->ws_split_bytes;
+}
+
+size_t ac3mi_transcode_workspace_plan(size_t frames, int n_in, int nfchans, int n_out)
+{
+    // what ac3mi_transcode_batch holds for a call (or tile) of `frames` frames: coefficient planes + block-switch flags and
+    // per-frame level flags (ensure_ws), the split front end's arrays (split_bytes), the s16 PCM between transform and
+    // encoder, the encoder's arrays (enc_ws_layout) - the same expressions the call allocates with
+    return frames * 6 * (size_t)n_in * 256 * sizeof(float) + (frames * 6 * (size_t)nfchans + 4 + frames) + split_bytes(frames) +
+           (frames * 1536 * (size_t)n_out * 2 + 512) + enc_ws_layout(frames * 6 * (size_t)n_out).need;
 }
 
 int ac3mi_xform_planes(const ac3mi_xform_desc *desc, int *n_in, int *n_out)
@@ -1204,14 +1237,9 @@ int ac3mi_encode_batch(ac3mi_ctx *ctx, const ac3mi_encode_desc *desc, const int1
         return rc;
     }
     const size_t rows = (size_t)n_streams * frames_per_stream * 6 * E.cfg.nch;
-    const size_t rows_pad = (rows + 255) & ~(size_t)255;
-    // mdct | raw exponents | encoded exponents | masking curves | exp_samples | strategies | exponent bits
-    const size_t off_expo = rows * 256 * 4, off_eexp = off_expo + rows * 256, off_emask = off_eexp + rows * 256;
-    const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
-    const size_t off_ebits = off_strat + rows_pad;
-    const size_t off_snr = off_ebits + rows_pad * 4;
-    const size_t off_memo = off_snr + rows_pad * 2;              // [S][F][2] int32 <= rows / 3 entries
-    const size_t need = off_memo + rows_pad * 6 + 1024;          // [S][F][8] uint32
+    const EncWs W = enc_ws_layout(rows);
+    const size_t off_eexp = W.off_eexp, off_emask = W.off_emask, off_shift = W.off_shift, off_strat = W.off_strat;
+    const size_t off_ebits = W.off_ebits, off_snr = W.off_snr, off_memo = W.off_memo, need = W.need;
     if (need > ctx->ws_enc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_enc);
@@ -1326,10 +1354,10 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         ctx->ws_tc_bytes = s16_bytes + 512;
     }
     int16_t *ws_s16 = (int16_t *)ctx->ws_tc;
-    const size_t rows = nfr * 6 * E.cfg.nch, rows_pad = (rows + 255) & ~(size_t)255;
-    const size_t off_eexp = rows * 256 * 4 + rows * 256, off_emask = off_eexp + rows * 256;
-    const size_t off_shift = off_emask + ((rows * 100 + 255) & ~(size_t)255), off_strat = off_shift + rows_pad;
-    const size_t off_ebits = off_strat + rows_pad, off_snr = off_ebits + rows_pad * 4, off_memo = off_snr + rows_pad * 2, need = off_memo + rows_pad * 6 + 1024;
+    const size_t rows = nfr * 6 * E.cfg.nch;
+    const EncWs W = enc_ws_layout(rows);
+    const size_t off_eexp = W.off_eexp, off_emask = W.off_emask, off_shift = W.off_shift, off_strat = W.off_strat;
+    const size_t off_ebits = W.off_ebits, off_snr = W.off_snr, off_memo = W.off_memo, need = W.need;
     if (need > ctx->ws_enc_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->ws_enc);

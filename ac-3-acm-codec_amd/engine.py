@@ -241,6 +241,11 @@ class Engine:
         self._check(self.lib.ac3mi_probe_mixed_rate(ctypes.c_void_p(self.ctx), int(waves_per_simd), ctypes.byref(v), ctypes.byref(s)))
         return v.value, s.value
 
+    def workspace_bytes(self):
+        """Device bytes the context's workspaces hold right now (ac3mi_workspace_bytes)."""
+        self.lib.ac3mi_workspace_bytes.restype = ctypes.c_size_t
+        return int(self.lib.ac3mi_workspace_bytes(ctypes.c_void_p(self.ctx)))
+
     def set_tile_frames(self, frames):
         """Workspace bound: batches above `frames` frames go through in tiles of whole streams (ac3mi_set_tile_frames)."""
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))
@@ -252,7 +257,7 @@ class Engine:
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
     def set_encode_mode(self, mode):
-        """0 = choose by batch size, 1 = one wavefront per stream / frame packs, 2 = one wavefront per audio block packs
+        """0 = choose by batch size, 1 = one wavefront per frame packs, 2 = one wavefront per audio block packs
         (ac3mi_set_encode_mode)."""
         self._check(self.lib.ac3mi_set_encode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X AC-3 block-transform engine.
 
-Workload (BASELINE.json configs[1]): batched decode transform — 65536 independent
-5.1 / 48 kHz frames per GPU, each 6 blocks x 6 channels of 256 dequantised coefficients,
-through IMDCT-512 + KBD window + overlap-add (the synthesis stage of a52_block).
-One "step" = one pass of ac3mi_imdct_batch over that batch, inputs resident in HBM.
+Metric (BASELINE.json): AC-3 5.1 @ 48 kHz frames/sec/GPU, decode + encode.
+Workload (BASELINE configs[4]'s per-GPU step at the batch size of configs[1]/[2]): 65536 independent 5.1 / 48 kHz /
+384 kbps one-frame streams per GPU, each decoded (a52_frame + 6 x a52_block to s16 PCM, what the ACM driver's decode
+loop does) and re-encoded (AC3_encode_frame) in ONE ac3mi_transcode_batch call, every step from FRESH stream state
+(decoder overlap 0 / dither seed 1, encoder history 0 / csnroffst 40: BASELINE's definition of configs[2] / [4]); frames
+in and frames out resident in HBM.  One "step" = state reset + one such call; `value` = frames of all ranks / wall time.
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
@@ -12,7 +14,8 @@ One "step" = one pass of ac3mi_imdct_batch over that batch, inputs resident in H
   spawns N child ranks of itself (before touching the GPU), one per device, and relays rank 0's line.
   Every rank owns its own 65536 streams - independent streams shard with no data-path collective: weak scaling.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md §6 for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md §5 for every field).  The transform-only number that headed the line in
+rounds 1-3 (BASELINE configs[1]: IMDCT-512 + overlap-add, the HBM-bound kernel) is `extra.transform_imdct512`.
 """
 import argparse
 import ctypes
@@ -25,8 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+METRIC = "AC-3 5.1@48kHz frames/sec/GPU (decode+encode); achieved HBM GB/s vs peak"      # BASELINE.json, verbatim
 FRAMES_PER_GPU = 65536
 N_CH = 6
+# algorithmic HBM bytes per transcoded frame, unfused definition: decode 1 536 in + 36 864 out, encode
+# 18 432 in + 1 536 out (a fused transcoder's minimum would be 3 072)
+TRANSCODE_BYTES_PER_FRAME = 38400 + 19968
 # algorithmic HBM bytes per frame of this workload:
 # 36 planes x 1 KiB coefficients in + 36 x 1 KiB PCM out + 6 ch x 128 floats overlap state r+w
 BYTES_PER_FRAME = 36 * 1024 + 36 * 1024 + 2 * N_CH * 128 * 4
@@ -146,35 +153,36 @@ def cpu_baseline_codec(frames, seconds_each=4.0):
             "encode": {"value": e_all, "unit": "frames/s", "cores": cores, "kind": "port", "one_thread": e_one}}
 
 
-def measured_traffic(frames):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/run_profile.sh),
-    only if they were taken at this batch size; else None."""
-    best = None
+def _newest_profile(suffix):
     pdir = os.path.join(ROOT, "profiles")
-    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if fn.endswith("_hbm_traffic.json"):
-            try:
-                d = json.load(open(os.path.join(pdir, fn)))
-                if d.get("frames_per_launch") == frames and "xform_kernel<false" in d.get("kernel", ""):
-                    best = d["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                pass
-    return best
+    names = sorted(fn for fn in (os.listdir(pdir) if os.path.isdir(pdir) else []) if fn.endswith(suffix))
+    for fn in reversed(names):
+        try:
+            d = json.load(open(os.path.join(pdir, fn)))
+            d["file"] = "profiles/" + fn
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def measured_traffic(frames, kernels=("xform_kernel<false, 4, false>",)):
+    """HBM bytes per launch of the named kernels, summed, from the newest committed rocprofv3 PMC summary
+    (profiles/*_hbm_traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, separate --pmc passes,
+    recipe profiles/run_r04.sh) - only if it was taken at this batch size and holds every kernel; else None."""
+    d = _newest_profile("_hbm_traffic.json")
+    if not d or d.get("frames_per_launch") != frames:
+        return None, None
+    try:
+        return sum(d["kernels"][k]["hbm_bytes_per_launch"] for k in kernels), d["file"]
+    except KeyError:
+        return None, d["file"]
 
 
 def instruction_mix():
-    """Per-frame instruction counts of the engine kernels from the committed rocprofv3 PMC summary
-    (profiles/*_instruction_mix.json, newest by name; recipe profiles/run_r02.sh).  None if absent."""
-    pdir = os.path.join(ROOT, "profiles")
-    names = sorted(fn for fn in (os.listdir(pdir) if os.path.isdir(pdir) else []) if fn.endswith("_instruction_mix.json"))
-    if not names:
-        return None
-    try:
-        d = json.load(open(os.path.join(pdir, names[-1])))
-        d["file"] = "profiles/" + names[-1]
-        return d
-    except (OSError, ValueError):
-        return None
+    """Per-frame instruction counts of the engine kernels from the newest committed rocprofv3 PMC summary
+    (profiles/*_instruction_mix.json; recipe profiles/run_r04.sh).  None if absent."""
+    return _newest_profile("_instruction_mix.json")
 
 
 N_SIMD = 256 * 4           # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md, chip-level parameters)
@@ -238,43 +246,77 @@ def ac3_crc_ok(frames):
     return int(np.count_nonzero(bad1 | (crc != 0)))
 
 
-def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=True, warm=True):
-    """Whole-path numbers for the other BASELINE configs on the same batch size (frames resident in HBM):
-    configs[2] encode (s16 PCM -> frames), bitstream decode (frames -> float PCM, both kernels) and
-    decode -> s16 -> re-encode (configs[4]'s per-GPU transcode step).  Each: frames/s of this rank's shard
-    (MAX-reduced time), algorithmic GB/s per SURVEY.md §8d, x realtime."""
+class Content:
+    """The synthetic batch every leg works on: seeded 5.1 PCM with level steps, its AC-3 frames (encoded once by the engine,
+    untimed, from fresh state), the two descriptors and the state arrays of the transcode legs."""
+
+    def __init__(self, pkg, eng, dev, S, rank):
+        import torch
+        self.S = S
+        self.enc = pkg.EncodeDesc(48000, 384000, 6)
+        self.fb = self.enc.frame_bytes()
+        self.dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=self.fb)
+        self.chmap = (0, 2, 1, 4, 5, 3)
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        self.gen = g
+        t = torch.arange(1536, device=dev, dtype=torch.float32)
+        ph = torch.rand((S, 1, 6), device=dev, generator=g) * 6.28
+        fr = 0.01 * torch.arange(1, 7, device=dev, dtype=torch.float32)
+        pcm = 8000.0 * torch.sin(ph + fr * t[None, :, None]) + (torch.rand((S, 1536, 6), device=dev, generator=g) - 0.5) * 4096
+        # level steps (x1 / x1/32 per 512-sample segment and channel) so that frames carry a realistic mix of new and
+        # reused exponent sets: a stationary signal would reuse block 0's exponents five times in every channel
+        env = torch.where(torch.rand((S, 3, 1, 6), device=dev, generator=g) < 0.5, 1.0, 1.0 / 32)
+        pcm = (pcm.reshape(S, 3, 512, 6) * env).reshape(S, 1536, 6)
+        self.pcm = pcm.round().clamp(-32768, 32767).to(torch.int16).reshape(S, 1, 1536, 6).contiguous()
+        self.last = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+        self.csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
+        self.csnr40 = torch.full((S,), 40, dtype=torch.int32, device=dev)
+        self.lfsr1 = torch.ones((S,), dtype=torch.int16, device=dev)
+        self.frames = torch.zeros((S, 1, self.fb), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        eng.encode_batch(self.enc, self.pcm, self.chmap, self.last, self.csnr, out=self.frames, wait_torch=False)
+        eng.sync()
+        # the transcode legs' own state and output
+        self.delay2 = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
+        self.lfsr2 = torch.ones((S,), dtype=torch.int16, device=dev)
+        self.last2 = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
+        self.csnr2 = torch.full((S,), 40, dtype=torch.int32, device=dev)
+        self.frames2 = torch.zeros((S, 1, self.fb), dtype=torch.uint8, device=dev)
+        self.status_tc = torch.zeros((S, 1), dtype=torch.int32, device=dev)
+        self.eng = eng
+
+    def reset_transcode(self):
+        """fresh stream state, on the engine's stream"""
+        e = self.eng
+        e.memset(self.last2)
+        e.copy(self.csnr2, self.csnr40)
+        e.memset(self.delay2)
+        e.copy(self.lfsr2, self.lfsr1)
+
+    def transcode(self):
+        self.eng.transcode_batch(self.dec, self.enc, self.frames, self.delay2, self.lfsr2, self.chmap, self.last2, self.csnr2,
+                                 out=self.frames2, status=self.status_tc, wait_torch=False)
+
+
+def secondary_timings(pkg, eng, dev, C, rank, dist, barrier, steps=20, checks=True, warm=True):
+    """The other BASELINE configs on the same batch (frames resident in HBM): configs[2] encode (s16 PCM -> frames),
+    bitstream decode (frames -> float PCM / s16), configs[3] (mixed block sizes + downmix), and the transcode with its
+    stream state carried on ("warm").  Each: frames/s of this rank's shard (MAX-reduced time), algorithmic GB/s per
+    SURVEY.md 8d, x realtime, and its ceilings (leg_rooflines)."""
     import torch
-    S = min(S, 65536)
-    enc = pkg.EncodeDesc(48000, 384000, 6)
-    fb = enc.frame_bytes()
-    g = torch.Generator(device=dev).manual_seed(99 + rank)
-    t = torch.arange(1536, device=dev, dtype=torch.float32)
-    ph = torch.rand((S, 1, 6), device=dev, generator=g) * 6.28
-    fr = 0.01 * torch.arange(1, 7, device=dev, dtype=torch.float32)
-    pcm = 8000.0 * torch.sin(ph + fr * t[None, :, None]) + (torch.rand((S, 1536, 6), device=dev, generator=g) - 0.5) * 4096
-    # level steps (x1 / x1/32 per 512-sample segment and channel) so that frames carry a realistic mix of new and
-    # reused exponent sets: a stationary signal would reuse block 0's exponents five times in every channel
-    env = torch.where(torch.rand((S, 3, 1, 6), device=dev, generator=g) < 0.5, 1.0, 1.0 / 32)
-    pcm = (pcm.reshape(S, 3, 512, 6) * env).reshape(S, 1536, 6)
-    pcm = pcm.round().clamp(-32768, 32767).to(torch.int16).reshape(S, 1, 1536, 6).contiguous()
-    last = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
-    csnr = torch.full((S,), 40, dtype=torch.int32, device=dev)
-    frames = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
-    dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=fb)
+    S = C.S
+    enc, dec, fb, chmap, pcm, frames, last, csnr = C.enc, C.dec, C.fb, C.chmap, C.pcm, C.frames, C.last, C.csnr
+    g = C.gen
     delay = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
     lfsr = torch.ones((S,), dtype=torch.int16, device=dev)
     out = torch.empty((S, 1, 6, 6, 256), dtype=torch.float32, device=dev)
     # one status array per leg: each leg's frame verdicts are read after all legs have run
     status = torch.zeros((S, 1), dtype=torch.int32, device=dev)
     status16 = torch.zeros((S, 1), dtype=torch.int32, device=dev)
-    status_tc = torch.zeros((S, 1), dtype=torch.int32, device=dev)
-    s16 = torch.empty((S, 6 * 256, 6), dtype=torch.int16, device=dev)
-    frames2 = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
-    chmap = (0, 2, 1, 4, 5, 3)
-    import ctypes
+    frames_e = torch.zeros((S, 1, fb), dtype=torch.uint8, device=dev)
 
-    def do_enc(src=pcm, dst=frames):
-        eng.encode_batch(enc, src, chmap, last, csnr, out=dst, wait_torch=False)
+    def do_enc():
+        eng.encode_batch(enc, pcm, chmap, last, csnr, out=frames_e, wait_torch=False)
 
     def do_dec():
         eng.decode_batch(dec, frames, delay, lfsr, out=out, status=status, wait_torch=False)
@@ -285,18 +327,6 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=Tr
 
     def do_dec16():
         eng.decode_s16_batch(dec, frames, delay16, lfsr16, out=out16, status=status16, wait_torch=False)
-
-    def do_cvt():
-        eng._check(eng.lib.ac3mi_convert_s16_batch(ctypes.c_void_p(eng.ctx), ctypes.c_void_p(out.data_ptr()),
-                                                  ctypes.c_void_p(s16.data_ptr()), 7 | 16, ctypes.c_size_t(S * 6)))
-
-    delay2 = torch.zeros((S, 6, 128), dtype=torch.float32, device=dev)
-    lfsr2 = torch.ones((S,), dtype=torch.int16, device=dev)
-    last2 = torch.zeros((S, 6, 256), dtype=torch.int16, device=dev)
-    csnr2 = torch.full((S,), 40, dtype=torch.int32, device=dev)
-
-    def do_transcode():
-        eng.transcode_batch(dec, enc, frames, delay2, lfsr2, chmap, last2, csnr2, out=frames2, status=status_tc, wait_torch=False)
 
     # BASELINE configs[3]: mixed short/long blocks (a quarter of the channel-blocks switched) with the 5.1 -> 2.0
     # downmix folded into the transform: 5 of the 6 planes in (liba52 drops the LFE), 2 planes out, 2 overlap tails
@@ -309,23 +339,14 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=Tr
     def do_mix():
         eng.imdct_batch(mixdesc, coef_mix, delay_mix, blksw=blksw_mix, out=out_mix, wait_torch=False)
 
-    # BASELINE configs[2] / configs[4] are defined on FRESH encoder state: every frame an independent stream with
-    # last_samples = 0 and csnroffst = 40 (ENC/ac3enc.cpp:921, 969, 1092 - the SNR-offset search starts from the stream's
-    # previous result, so a stream that re-encodes the same content starts at its own optimum from pass 2 on).  "cold" =
-    # state put back to those values on the engine's stream before every timed pass, outside the timer (the leg's headline);
-    # "warm" = the passes run on, each continuing the streams of the one before (the search's best case).
-    csnr40 = torch.full((S,), 40, dtype=torch.int32, device=dev)
-    lfsr1 = torch.ones((S,), dtype=torch.int16, device=dev)
-
+    # BASELINE configs[2] is defined on FRESH encoder state: every frame an independent stream with last_samples = 0 and
+    # csnroffst = 40 (ENC/ac3enc.cpp:921, 969, 1092 - the SNR-offset search starts from the stream's previous result, so a
+    # stream that re-encodes the same content starts at its own optimum from pass 2 on).  "cold" = state put back to those
+    # values on the engine's stream before every timed pass, outside the timer (the leg's figure); "warm" = the passes run
+    # on, each continuing the streams of the one before (the search's best case).
     def reset_enc():
         eng.memset(last)
-        eng.copy(csnr, csnr40)
-
-    def reset_transcode():
-        eng.memset(last2)
-        eng.copy(csnr2, csnr40)
-        eng.memset(delay2)
-        eng.copy(lfsr2, lfsr1)
+        eng.copy(csnr, C.csnr40)
 
     def timed(fn, reset=None):
         torch.cuda.synchronize(dev)
@@ -357,8 +378,7 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=Tr
     for name, fn, nbytes, reset in (("transform_downmix_mixed_blocks", do_mix, 30720 + 12288 + 2 * 1024, None),   # the LFE plane is not mixed in
                                     ("encode", do_enc, 18432 + 1536 + 2 * 3072, reset_enc),
                                     ("decode", do_dec, 1536 + 36864 + 2 * 3072, None),
-                                    ("decode_s16", do_dec16, 1536 + 18432 + 2 * 3072, None),
-                                    ("transcode", do_transcode, 38400 + 19968, reset_transcode)):
+                                    ("decode_s16", do_dec16, 1536 + 18432 + 2 * 3072, None)):
         ms = timed(fn, reset)
         fps = S / (ms * 1e-3)
         res[name] = {"frames_per_s_per_gpu": fps, "ms_per_pass": ms, "algorithmic_GBps": nbytes * fps / 1e9,
@@ -366,53 +386,92 @@ def secondary_timings(pkg, eng, dev, S, rank, dist, barrier, steps=20, checks=Tr
                      "algorithmic_bytes_per_frame": nbytes}
         if reset is not None:
             res[name]["state"] = "cold: encoder history 0 and csnroffst 40 before every timed pass (BASELINE's definition)"
-            if not warm:
-                continue
-            wms = timed(fn, None)
-            res[name]["warm"] = {"frames_per_s_per_gpu": S / (wms * 1e-3), "ms_per_pass": wms,
-                                 "state": "warm: every pass continues the streams of the pass before (same content: the search starts at its optimum)"}
-    # the issue ceiling of the instruction-bound kernels: plain VALU instructions per second and SIMD, chip-wide load
-    rate = eng.probe_valu_rate()
-    srate = eng.probe_salu_rate()
-    res["salu_probe"] = {"ginst_per_s_per_simd": srate,
-                         "note": "scalar instructions per second and SIMD (one scalar unit per CU, shared by its four SIMDs), chip-wide load"}
-    res["valu_probe"] = {"ginst_per_s_per_simd": rate,
-                         "note": "plain 32-bit VALU instructions one SIMD sustains with all SIMDs busy (8 wavefronts each); "
-                                 "the valu_issue rooflines of the legs are priced against this x %d SIMDs" % N_SIMD}
-    # ... and what the two pipes sustain TOGETHER at the integer kernels' own mix (three vector instructions per scalar one) and
-    # occupancies: the vector pipe reaches its own ceiling only at 8 wavefronts per SIMD; the scalar stream rides along
-    res["mixed_probe"] = {"note": "10^9 (vector, scalar) instructions per second and SIMD, every wavefront issuing 3 vector per scalar instruction "
-                                  "on independent registers (ac3mi_probe_mixed_rate); the packers run 4 wavefronts per SIMD, the parse kernel 5, "
-                                  "enc_mdct_kernel 7, mant_kernel 8",
-                          "by_wavefronts_per_simd": {str(w): list(eng.probe_mixed_rate(w)) for w in (4, 5, 6, 7, 8)}}
-    mix = instruction_mix()
-    for name in ("encode", "decode", "decode_s16", "transcode", "transform_downmix_mixed_blocks"):
-        res[name]["roofline"] = leg_rooflines(name, res[name]["algorithmic_bytes_per_frame"], res[name]["frames_per_s_per_gpu"], rate, mix, srate)
+            if warm:
+                wms = timed(fn, None)
+                res[name]["warm"] = {"frames_per_s_per_gpu": S / (wms * 1e-3), "ms_per_pass": wms,
+                                     "state": "warm: every pass continues the streams of the pass before (same content: the search starts at its optimum)"}
+    if warm:
+        wms = timed(C.transcode, None)
+        res["transcode_warm"] = {"frames_per_s_per_gpu": S / (wms * 1e-3), "ms_per_pass": wms,
+                                 "state": "the headline's call with the stream state carried on from pass to pass (the search's best case)"}
     # ---- untimed epilogue: every leg's verdict on the whole batch, from its own buffers ----
     eng.sync()
     torch.cuda.synchronize(dev)
     res["decode"]["all_frames_ok"] = int((status & 0x1ff).max().item()) == 0
     res["decode_s16"]["all_frames_ok"] = int((status16 & 0x1ff).max().item()) == 0
-    res["transcode"]["all_frames_decoded_ok"] = int((status_tc & 0x1ff).max().item()) == 0
-    enc_host = frames.cpu().numpy().reshape(S, -1)[:, :fb]
-    tc_host = frames2.cpu().numpy().reshape(S, -1)[:, :fb]
+    enc_host = frames_e.cpu().numpy().reshape(S, -1)[:, :fb]
     res["encode"]["frames_failing_crc"] = ac3_crc_ok(enc_host)
-    res["transcode"]["frames_failing_crc"] = ac3_crc_ok(tc_host)
     res["encode"]["all_frames_ok"] = res["encode"]["frames_failing_crc"] == 0
-    res["transcode"]["all_frames_ok"] = res["transcode"]["frames_failing_crc"] == 0 and res["transcode"]["all_frames_decoded_ok"]
     if rank == 0 and checks:
         res["encode"]["bit_exact_vs_oracle"] = check_against_oracle(pkg, eng, dev, enc, dec, chmap, pcm)
-    res["_frames"] = enc_host[:64].reshape(64, 1, fb).copy()      # for the CPU rates beside these legs (dropped from the line)
-    if os.environ.get("AC3MI_BENCH_MILLION", "1") == "1" and S >= 65536:
-        try:
-            res["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, frames)
-        except RuntimeError as e:                       # (a GPU whose memory other jobs hold: the leg is left out, the line says why)
-            res["transcode_million_streams"] = {"skipped": str(e)[:200]}
-    if dist is None and checks:           # host-side work on up to 16 threads: single-process runs only
-        res["stream_layer"] = stream_layer_timing(pkg, eng, frames[:8192].cpu().numpy())
     res["note"] = ("secondary timings on %d frames/GPU (5.1, 48 kHz, 384 kbps); encode and the decode front end are "
-                   "integer/latency-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
+                   "instruction-bound, not HBM-bound: hbm_frac is reported for completeness" % S)
     return res
+
+
+def per_stream_curve(eng, C, sizes=(1, 64, 512, 2048, 8192, 65536), passes=8):
+    """north_star: ">= 50x realtime per stream".  One frame is 32 ms of audio, so a stream runs at 32 ms / (time of the round
+    that advances it by a frame): rounds of S one-frame streams through ac3mi_transcode_batch, each round from fresh stream
+    state (reset outside the timer), HIP events on the engine's stream.  Small rounds take the fused decoder and the block
+    packer (ac3mi.h), large ones the split kernels - whatever the engine picks for the batch."""
+    rows = []
+    for S in sizes:
+        if S > C.S:
+            continue
+        fr, st = C.frames[:S], C.status_tc[:S]
+        d, l, h, c, o = C.delay2[:S], C.lfsr2[:S], C.last2[:S], C.csnr2[:S], C.frames2[:S]
+
+        def go():
+            eng.transcode_batch(C.dec, C.enc, fr, d, l, C.chmap, h, c, out=o, status=st, wait_torch=False)
+
+        def reset():
+            eng.memset(h)
+            eng.copy(c, C.csnr40[:S])
+            eng.memset(d)
+            eng.copy(l, C.lfsr1[:S])
+        reset()
+        go()
+        eng.sync()
+        best, tot = 1e9, 0.0
+        for _ in range(passes):
+            reset()
+            eng.timer_start()
+            go()
+            ms = eng.timer_stop()
+            best, tot = min(best, ms), tot + ms
+        ms = tot / passes
+        rows.append({"streams": S, "ms_per_round": ms, "best_ms": best, "realtime_x_per_stream": 32.0 / ms,
+                     "aggregate_frames_per_s": S / (ms * 1e-3)})
+    ok = [r for r in rows if r["realtime_x_per_stream"] >= 50.0]
+    best = max(ok, key=lambda r: r["streams"]) if ok else None
+    return {"rounds": rows,
+            "largest_round_at_50x_realtime_per_stream": best,
+            "note": "decode + encode of one frame per stream and round (ac3mi_transcode_batch, fresh state, frames resident in HBM); "
+                    "a stream's realtime factor = 32 ms / round time; rounds measured: the operating point lies between the last "
+                    "round at >= 50x and the next one"}
+
+
+def dropin_single_stream(frames_host):
+    """What ONE stream gets through the drop-in loop the ACM driver runs (src/AC3ACM.cpp:1498-1581, 1762): a plain-C host
+    (tools/ac3mi_loop.c, built by tools/Makefile against include/ac3mi_dropin.h) calls a52_syncinfo / a52_frame / 6 x a52_block
+    + the MapTab converter and AC3_encode_frame frame by frame - one launch sequence per frame, PCIe both ways."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "ac3mi_loop")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/ac3mi_loop not built"}
+    with tempfile.NamedTemporaryFile(suffix=".ac3", delete=False) as f:
+        f.write(frames_host.tobytes())
+        name = f.name
+    try:
+        p = subprocess.run([exe, name, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        if p.returncode != 0:
+            return {"skipped": "ac3mi_loop rc %d: %s" % (p.returncode, p.stderr.decode()[-200:])}
+        return json.loads(p.stdout.decode().strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError) as e:
+        return {"skipped": str(e)[:200]}
+    finally:
+        os.unlink(name)
 
 
 def check_against_oracle(pkg, eng, dev, enc, dec, chmap, pcm, n_enc=4096, n_dec=256):
@@ -470,7 +529,7 @@ def million_stream_transcode(pkg, eng, dev, frames, n_streams=1 << 20, passes=2)
     """BASELINE configs[4], one GPU's share (8M streams / 8 GPUs): decode -> s16 -> re-encode of 2^20 independent streams,
     one frame each per pass, every pass from fresh stream state (configs[4]'s definition; state reset outside the timer).
     AC3MI_BENCH_MILLION=0 skips it (takes ~1 s of GPU time and ~30 GB of HBM: frames in/out 3 GB, carry-over state 6.5 GB,
-    the engine's tiled workspace ~20 GB)."""
+    the engine's tile-bounded workspaces ~20 GB: `engine_workspace_GB` is what the context really holds, ac3mi_workspace_bytes)."""
     import torch
     S0, _, fb = frames.shape
     big = frames.repeat((n_streams + S0 - 1) // S0, 1, 1)[:n_streams].contiguous()
@@ -485,7 +544,7 @@ def million_stream_transcode(pkg, eng, dev, frames, n_streams=1 << 20, passes=2)
     chmap = (0, 2, 1, 4, 5, 3)
     csnr40 = torch.full((n_streams,), 40, dtype=torch.int32, device=dev)
     lfsr1 = torch.ones((n_streams,), dtype=torch.int16, device=dev)
-    free0, total = torch.cuda.mem_get_info(dev)
+    _, total = torch.cuda.mem_get_info(dev)
     torch.cuda.synchronize(dev)
     eng.transcode_batch(dec, enc, big, delay, lfsr, chmap, last, csnr, out=out, status=status, wait_torch=False)
     ms = 0.0
@@ -498,11 +557,12 @@ def million_stream_transcode(pkg, eng, dev, frames, n_streams=1 << 20, passes=2)
         eng.transcode_batch(dec, enc, big, delay, lfsr, chmap, last, csnr, out=out, status=status, wait_torch=False)
         ms += eng.timer_stop()
     ms /= passes
-    free1, _ = torch.cuda.mem_get_info(dev)
     ok = int((status & 0x1ff).max().item()) == 0
     same = bool(torch.equal(out[:S0], out[S0:2 * S0])) if n_streams >= 2 * S0 else None
+    plan = pkg.sharding.plan_transcode_bytes(n_streams)
     return {"streams": n_streams, "ms_per_pass": ms, "frames_per_s_per_gpu": n_streams / (ms * 1e-3), "all_frames_ok": ok, "state": "cold (fresh stream state every pass)",
-            "replicas_agree_across_tiles": same, "engine_workspace_GB": (free0 - free1) / 1e9, "hbm_total_GB": total / 1e9}
+            "replicas_agree_across_tiles": same, "engine_workspace_GB": eng.workspace_bytes() / 1e9,
+            "planned_GB": {"workspace": plan["workspace"] / 1e9, "state_and_io": plan["state_and_io"] / 1e9}, "hbm_total_GB": total / 1e9}
 
 
 def stream_layer_timing(pkg, eng, frames, rounds=20):
@@ -599,8 +659,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames (independent streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary decode/encode/transcode timings")
-    ap.add_argument("--no-checks", action="store_true", help="skip the untimed oracle check and the stream-layer leg (profiling runs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary timings (transform, encode, decode, curves)")
+    ap.add_argument("--no-checks", action="store_true", help="skip the untimed oracle check and the host-side legs (profiling runs)")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm (state carried on) passes of the encode / transcode legs (PMC runs)")
     ap.add_argument("--launch-check", action="store_true", help="N-rank rendezvous and reductions only (gloo, no GPU)")
     ap.add_argument("--job-streams", type=int, default=0, help="--launch-check: streams of the whole job (default 65536 per rank)")
@@ -635,22 +695,20 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = None if rehearse else dev                  # where the reductions' tensors live
 
     pkg = importlib.import_module("ac-3-acm-codec_amd")
     eng = pkg.Engine(local_rank)                      # fails loudly without libac3mi.so / a GPU
-    desc = pkg.XformDesc(acmod=7, lfeon=1, output=7 | 16, bias=0.0)
 
     S = args.frames
     # this rank's contiguous shard of the job's S x world independent streams (no data-path collective)
     lo, hi = pkg.sharding.shard(S * world, world, rank)
     assert hi - lo == S
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    coef = torch.randn((S, 1, 6, N_CH, 256), device=dev, generator=g, dtype=torch.float32) * (2.0 ** -8)
-    delay = torch.zeros((S, N_CH, 128), device=dev, dtype=torch.float32)
-    out = torch.empty((S, 1, 6, N_CH, 256), device=dev, dtype=torch.float32)
+    C = Content(pkg, eng, dev, S, rank)               # seeded PCM -> this rank's AC-3 frames (untimed)
 
     def step():
-        eng.imdct_batch(desc, coef, delay, None, out=out, wait_torch=False)
+        C.reset_transcode()                           # fresh streams: part of the step
+        C.transcode()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -664,36 +722,141 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    eng.timer_start()
     for _ in range(args.steps):
         step()
-    kernel_ms = eng.timer_stop() / args.steps          # HIP events on the engine's own stream
     barrier()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
+    dt = dt_own
+    per_rank = [S * args.steps / dt_own]
     if dist is not None:
-        t = torch.tensor([dt, kernel_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt_own], device=rdev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [S * args.steps / float(x[0]) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
+        dt = float(t[0])
+    # the call alone (no state reset), HIP events on the engine's own stream, one pair per call: what the rooflines divide by
+    n_ev = max(1, min(args.steps, 20))
+    call_ms = 0.0
+    for _ in range(n_ev):
+        C.reset_transcode()
+        eng.timer_start()
+        C.transcode()
+        call_ms += eng.timer_stop()
+    call_ms /= n_ev
+    if dist is not None:
+        t = torch.tensor([call_ms], device=rdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        call_ms = float(t[0])
+    eng.sync()
+    torch.cuda.synchronize(dev)
+    tc_ok_decode = int((C.status_tc & 0x1ff).max().item()) == 0
+    tc_host = C.frames2.cpu().numpy().reshape(S, -1)[:, :C.fb]
+    tc_bad_crc = ac3_crc_ok(tc_host)
 
-    # the guide's float4 copy on this box in this run: what a read+write stream reaches at best (rank 0, untimed)
-    copy_gbs = None
-    if rank == 0:
-        try:
-            copy_gbs = eng.probe_copy_rate(1 << 31)
-        except Exception:                                   # (an older library: the line simply lacks the field)
-            copy_gbs = None
+    # ---- the ceilings this run is priced against: probes of this very run + the committed PMC summaries ----
+    rate = eng.probe_valu_rate()
+    srate = eng.probe_salu_rate()
+    mix = instruction_mix()
+    fps_call = S / (call_ms * 1e-3)
+    rl = leg_rooflines("transcode", TRANSCODE_BYTES_PER_FRAME, fps_call, rate, mix, srate)
+    tc_kernels = (mix or {}).get("legs", {}).get("transcode", [])
+    traffic, traffic_file = measured_traffic(S, tc_kernels) if tc_kernels else (None, None)
+    hbm = dict(rl["hbm"])
+    hbm["traffic"] = traffic
+    hbm["traffic_source"] = ("sum over the call's kernels of 2 x FETCH_SIZE + WRITE_SIZE per launch, committed rocprofv3 --pmc passes at this batch "
+                             "size (%s), not collected in this run" % traffic_file)
+    hbm["fused_minimum_bytes_per_frame"] = 3072
+    issue = rl.get("issue")
+    roofline = {
+        "bound": "issue",
+        "achieved": (rl["valu_issue"]["achieved"] + rl["salu_issue"]["achieved"]) if issue else None,
+        "peak": (rl["valu_issue"]["peak"]) if issue else None,
+        "unit": "Ginst/s",
+        "frac": issue["frac"] if issue else None,
+        "traffic": traffic,
+        "note": "decode + encode is bound by instruction issue, not by HBM (hbm.frac): frac = share of the chip's vector issue slots the "
+                "call's vector instructions need at its measured rate + the same for the scalar unit (committed per-frame counts x this "
+                "run's rate / this run's probe ceilings); `achieved` = vector + scalar instructions per second, `peak` = the vector probe",
+        "hbm": hbm,
+        "issue": {"valu": rl.get("valu_issue"), "salu": rl.get("salu_issue"), "frac": issue["frac"] if issue else None},
+        "kernels": tc_kernels,
+        "call_ms": call_ms,
+        "valu_probe_ginst_per_s_per_simd": rate,
+        "salu_probe_ginst_per_s_per_simd": srate,
+    }
 
-    # ---- secondary timings (not the headline): full frame decode, encode, transcode ----
+    # ---- secondary numbers (not the headline) ----
     extra = None
     if not args.no_extra:
-        extra = secondary_timings(pkg, eng, dev, S, rank, dist, barrier, checks=not args.no_checks, warm=not args.no_warm)
+        extra = {}
+        # BASELINE configs[1], the HBM-bound kernel (the headline of rounds 1-3): IMDCT-512 + window + overlap-add
+        desc = pkg.XformDesc(acmod=7, lfeon=1, output=7 | 16, bias=0.0)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        coef = torch.randn((S, 1, 6, N_CH, 256), device=dev, generator=g, dtype=torch.float32) * (2.0 ** -8)
+        delay = torch.zeros((S, N_CH, 128), device=dev, dtype=torch.float32)
+        out = torch.empty((S, 1, 6, N_CH, 256), device=dev, dtype=torch.float32)
+        torch.cuda.synchronize(dev)
+        for _ in range(3):
+            eng.imdct_batch(desc, coef, delay, None, out=out, wait_torch=False)
+        barrier()
+        eng.timer_start()
+        for _ in range(50):
+            eng.imdct_batch(desc, coef, delay, None, out=out, wait_torch=False)
+        kernel_ms = eng.timer_stop() / 50
+        barrier()
+        if dist is not None:
+            t = torch.tensor([kernel_ms], device=rdev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            kernel_ms = float(t[0])
+        del coef, delay, out
+        achieved = BYTES_PER_FRAME * S / (kernel_ms * 1e-3) / 1e9
+        copy_gbs = None
+        if rank == 0:
+            try:
+                copy_gbs = eng.probe_copy_rate(1 << 31)     # the guide's float4 copy on this box in this run (untimed)
+            except Exception:
+                copy_gbs = None
+        xt, xt_file = measured_traffic(S)
+        extra["transform_imdct512"] = {
+            "workload": "BASELINE configs[1]: batched decode transform, %d independent 5.1/48kHz frames per GPU, IMDCT-512 + KBD window + "
+                        "overlap-add, coefficients and PCM resident in HBM" % S,
+            "frames_per_s_per_gpu": S / (kernel_ms * 1e-3), "ms_per_pass": kernel_ms, "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": xt, "traffic_source": "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch size (%s)" % xt_file,
+                         "kernel": "ac3mi::xform_kernel<false, 4, false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
+                         "copy_probe": None if not copy_gbs else {
+                             "GBps": copy_gbs, "frac_of_copy": achieved / copy_gbs,
+                             "note": "bare float4 copy, one element per lane, 2 GiB per array, measured in this run (ac3mi_probe_copy_rate): "
+                                     "the practical ceiling of a read+write stream on this box; `peak` stays the spec number"}}}
+        extra.update(secondary_timings(pkg, eng, dev, C, rank, dist, barrier, checks=not args.no_checks, warm=not args.no_warm))
+        for name in ("encode", "decode", "decode_s16", "transform_downmix_mixed_blocks"):
+            extra[name]["roofline"] = leg_rooflines(name, extra[name]["algorithmic_bytes_per_frame"], extra[name]["frames_per_s_per_gpu"], rate, mix, srate)
+        extra["mixed_probe"] = {"note": "10^9 (vector, scalar) instructions per second and SIMD, every wavefront issuing 3 vector per scalar instruction "
+                                        "on independent registers (ac3mi_probe_mixed_rate), by wavefronts per SIMD",
+                                "by_wavefronts_per_simd": {str(w): list(eng.probe_mixed_rate(w)) for w in (4, 5, 6, 7, 8)}}
+        if rank == 0:
+            extra["per_stream_curve"] = per_stream_curve(eng, C)
+        million_skip = None
+        if os.environ.get("AC3MI_BENCH_MILLION", "1") != "1":
+            million_skip = "AC3MI_BENCH_MILLION=0"
+        elif S < 65536:
+            million_skip = "--frames below 65536"
+        else:
+            try:
+                extra["transcode_million_streams"] = million_stream_transcode(pkg, eng, dev, C.frames)
+            except RuntimeError as e:                       # (a GPU whose memory other jobs hold: the leg is left out, the line says why)
+                million_skip = str(e)[:200]
+        extra["transcode_million_streams_skipped"] = million_skip
+        if dist is None and not args.no_checks:             # host-side legs: single-process runs only
+            extra["stream_layer"] = stream_layer_timing(pkg, eng, C.frames[:8192].cpu().numpy())
+            extra["dropin_single_stream"] = dropin_single_stream(tc_host[:48])
 
     if rank == 0:
-        total_frames = S * world * args.steps
-        value = total_frames / dt
-        achieved = BYTES_PER_FRAME * S / (kernel_ms * 1e-3) / 1e9
+        value = S * world * args.steps / dt
         line = {
-            "metric": "AC-3 5.1@48kHz frames/sec (batched decode transform: IMDCT-512 + window + overlap-add)",
+            "metric": METRIC,
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -703,48 +866,43 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32+i32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: batched decode, %d independent 5.1/48kHz frames per GPU, "
-                            "IMDCT-512 + KBD window + overlap-add, coefficients and PCM resident in HBM" % S,
+                "workload": "BASELINE configs[4]'s per-GPU step at configs[1]/[2]'s batch size: %d independent 5.1/48kHz/384kbps one-frame "
+                            "streams per GPU, decode (frames -> s16 PCM) + re-encode (AC3_encode_frame) in one ac3mi_transcode_batch call, "
+                            "every step from fresh stream state (reset inside the step), frames in and out resident in HBM" % S,
                 "frames_per_gpu": S,
                 "channels": N_CH,
                 "blocks_per_frame": 6,
                 "parallelism": "streams sharded over %d GPU(s), no collective" % world,
+                "frames_per_s_per_gpu": value / world,
                 "realtime_x_per_gpu": value / world * 0.032,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(S),
-                "traffic_source": "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch size "
-                                  "(profiles/*_hbm_traffic.json), not collected in this run",
-                "kernel": "ac3mi::xform_kernel<false, 4, false>",
-                "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_launch": BYTES_PER_FRAME * S,
-                "copy_probe": None if not copy_gbs else {
-                    "GBps": copy_gbs, "frac_of_copy": achieved / copy_gbs,
-                    "note": "bare float4 copy, one element per lane, 2 GiB per array, measured in this run "
-                            "(ac3mi_probe_copy_rate): the practical ceiling of a read+write stream on this box; `peak` stays the spec number"},
-            },
+            "per_rank_frames_per_s": per_rank,
+            "roofline": roofline,
+            "all_frames_ok": tc_ok_decode and tc_bad_crc == 0,
+            "frames_failing_crc": tc_bad_crc,
+            # (kept from rounds 2-3 for readers of older lines: the same number as `value` per GPU, from the event-timed call)
+            "decode_plus_encode_frames_per_s": fps_call * world,
+            "decode_plus_encode_hbm_frac": hbm["frac"],
         }
         if extra is not None:
             line["extra"] = extra
-            # BASELINE's metric wording, "frames/sec/GPU (decode+encode)": the one-call transcode, fresh stream state
-            line["decode_plus_encode_frames_per_s"] = extra["transcode"]["frames_per_s_per_gpu"] * world
-            line["decode_plus_encode_hbm_frac"] = extra["transcode"]["hbm_frac"]
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-            if extra is not None and "_frames" in extra:
-                extra["cpu"] = cpu_baseline_codec(extra.pop("_frames"))
+        if not args.no_cpu_baseline:
+            # (N > 1: rank 0 measures it after the barrier, the other ranks are done)
+            cpu = cpu_baseline_codec(tc_host[:64].reshape(64, 1, C.fb).copy())
+            d, e = cpu["decode"]["value"], cpu["encode"]["value"]
+            line["cpu_baseline"] = {
+                "value": 1.0 / (1.0 / d + 1.0 / e), "unit": "frames/s", "cores": cpu["decode"]["cores"], "kind": "port",
+                "sample": "the same frames through the CPU path, decode then encode, whole loops in C on %d threads, ~4 s each: decode = the "
+                          "reference's own liba52 (kind %s, %.0f frames/s), encode = the encoder oracle (kind port: ac3enc.cpp does not "
+                          "build here, %.0f frames/s); value = 1 / (1/decode + 1/encode)" % (cpu["decode"]["cores"], cpu["decode"]["kind"], d, e),
+                "parts": cpu}
+            if extra is not None and world == 1:
+                extra["transform_imdct512"]["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None
-        if extra is not None:
-            extra.pop("_frames", None)
         print(json.dumps(line), flush=True)
 
     eng.close()

@@ -157,12 +157,12 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
 #define AC3MI_STATUS_REUSE0 0x200u
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 
-/* How ac3mi_encode_batch / ac3mi_transcode_batch pack a frame once its SNR offsets are found (new; same bytes either way):
- *   1  one wavefront per stream searches and packs its frames in order (few long streams: searches per stream, then one
- *      wavefront per frame packs);
- *   2  searches per stream, then a workgroup of six wavefronts per frame, one per audio block: every block's first bit
- *      follows from bit counts, so the six pack at once into the frame they share in LDS (a third less latency per frame;
- *      ahead for batches of up to about 1 000 frames);
+/* How ac3mi_encode_batch / ac3mi_transcode_batch pack a frame once its SNR offsets are found (new; same bytes either way -
+ * the searches always run first, one wavefront per stream, frames in order):
+ *   1  one wavefront per frame packs it;
+ *   2  a workgroup of six wavefronts per frame, one per audio block: every block's first bit follows from bit counts, so
+ *      the six pack at once into the frame they share in LDS (a third less latency per frame; ahead for batches of up to
+ *      about 1 000 frames);
  *   0  (default) 2 for up to 1 024 frames per call, else 1. */
 int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode);
 
@@ -173,6 +173,14 @@ int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode);
  * streams, so the workspaces stop growing with the batch: a million-stream call needs its own input, output and state
  * arrays plus a fixed ~20 GB.  Default 131072; 0 = never tile.  Calls that ask for stage taps are not tiled. */
 int ac3mi_set_tile_frames(ac3mi_ctx *ctx, long long frames);
+
+/* Workspace accounting (new).  ac3mi_workspace_bytes: device bytes the context's workspaces hold right now (they only grow,
+ * up to the tile bound).  ac3mi_transcode_workspace_plan: what ac3mi_transcode_batch holds for a call - or, above the tile
+ * bound, a tile - of `frames` frames with n_in coded planes (lfe included), nfchans full-bandwidth channels and n_out output
+ * / encoder channels; pure arithmetic on the allocation's own expressions, callable without a context or a GPU (the
+ * multi-GPU planner, ac-3-acm-codec_amd/sharding.py, sizes a rank's shard with it). */
+size_t ac3mi_workspace_bytes(const ac3mi_ctx *ctx);
+size_t ac3mi_transcode_workspace_plan(size_t frames, int n_in, int nfchans, int n_out);
 
 /* Number of input planes (lfeon + fbw channels of acmod) and of output planes
  * for a descriptor; negative on an invalid combination. */
