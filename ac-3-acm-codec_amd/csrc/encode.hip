@@ -662,21 +662,24 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
                 if (P.slot) P.last[((size_t)P.slot[s] * 6 + ch) * 256 + j] = newv[k];
                 else P.last[((size_t)s * P.nch + ch) * 256 + j] = newv[k];
             }
-            win_[k] = (int16_t)(__mul24(oldv[k], wa[k]) >> 15);
-            win_[4 + k] = (int16_t)(__mul24(newv[k], wb[k]) >> 15);
+            // (a 16-bit sample times a window value in 0 .. 32767, >> 15, is a 16-bit value again: no truncation to restate)
+            win_[k] = __mul24(oldv[k], wa[k]) >> 15;
+            win_[4 + k] = __mul24(newv[k], wb[k]) >> 15;
             oldv[k] = newv[k];
         }
-        // ---- block floating point (:1697-1700) ----
+        // ---- block floating point (:1697-1700): v from the position of the largest magnitude's top bit (the reference ORs the
+        //      magnitudes, :1570-1596; the maximum has the same top bit) ----
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc |= win_[k] < 0 ? -win_[k] : win_[k];
-        acc = wave_or(acc);
+        for (int k = 0; k < 8; k++) acc = max(acc, max(win_[k], -win_[k]));
+        acc = wave_max_nonneg(acc);
         int v = 14 - ilog2u((unsigned)acc);
         if (v < 0) v = 0;
         const int shift = v - 9;
         int O[4], N[4];                                                     // in[jpos[k]], in[256 + jpos[k]] as 16-bit values
+        // (|x| << v < 2^15 by the choice of v, or v = 0: the shifted values are 16-bit values already)
 #pragma unroll
-        for (int k = 0; k < 4; k++) { O[k] = (int16_t)(win_[k] * (1 << v)); N[k] = (int16_t)(win_[4 + k] * (1 << v)); }
+        for (int k = 0; k < 4; k++) { O[k] = win_[k] << v; N[k] = win_[4 + k] << v; }
         // ---- rotation + pre-rotation (:578-591) of the points L (-> p) and L + 64 (-> q) ----
         int pr, pi, qr, qi;
         {

@@ -35,6 +35,16 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
     return wave_last(v);
 }
 
+// maximum of all lanes' non-negative values, wave-uniform
+__device__ __forceinline__ int wave_max_nonneg(int v)
+{
+#define AC3MI_STEP(ctrl, rows, bc) { const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, bc); v = t > v ? t : v; }
+    AC3MI_STEP(0x111, 0xf, true) AC3MI_STEP(0x112, 0xf, true) AC3MI_STEP(0x114, 0xf, true) AC3MI_STEP(0x118, 0xf, true)
+    AC3MI_STEP(0x142, 0xa, false) AC3MI_STEP(0x143, 0xc, false)
+#undef AC3MI_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // prefix minimum / maximum (lanes shifted in from outside a row keep the identity)
 __device__ __forceinline__ int wave_incl_scan_min(int v)
 {

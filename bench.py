@@ -640,9 +640,16 @@ def launch_check(job_streams=0):
     plan = sh.plan_transcode_bytes(hi - lo)
     tmax, pmax = sh.reduce_max([0.001 * (rank + 1), float(plan["total"])], dist if world > 1 else None)
     total, fits = sh.reduce_sum([hi - lo, 1.0 if plan["fits"] else 0.0], dist if world > 1 else None)
+    per_rank = [float(hi - lo)]
+    if world > 1:                   # what main() does with every rank's own rate: gathered, not only MAX-reduced
+        t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x[0]) for x in allt]
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "streams_total": int(total), "max_time": tmax,
-                          "local_rank": local_rank, "max_rank_hbm_plan_bytes": pmax, "ranks_that_fit_288GB": int(fits)}), flush=True)
+                          "local_rank": local_rank, "max_rank_hbm_plan_bytes": pmax, "ranks_that_fit_288GB": int(fits),
+                          "per_rank_streams": per_rank}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

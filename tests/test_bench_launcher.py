@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from tests import _harness as H
 
 
@@ -24,6 +26,7 @@ def test_self_launch_two_ranks():
     assert d["launch_check"] and d["n_gpus"] == 2
     assert d["streams_total"] == 2 * 65536           # SUM over ranks of the contiguous shards = the whole job
     assert abs(d["max_time"] - 0.002) < 1e-12        # MAX over ranks
+    assert d["per_rank_streams"] == [65536.0, 65536.0]       # every rank's own figure, gathered
 
 
 def test_single_rank_needs_no_rendezvous():
@@ -45,3 +48,17 @@ def test_eight_ranks_plan_the_8m_stream_job():
     assert d["n_gpus"] == 8 and d["streams_total"] == 8 * (1 << 20)
     assert d["ranks_that_fit_288GB"] == 8
     assert 20e9 < d["max_rank_hbm_plan_bytes"] < 60e9
+
+
+@pytest.mark.gpu
+def test_two_rank_line_carries_every_ranks_rate_and_the_cpu_baseline():
+    """The N-rank code path of the real bench on the one-GPU box: both ranks on device 0 over gloo (AC3MI_BENCH_REHEARSE=1;
+    RCCL refuses two ranks on one device).  The line must name BASELINE's metric, carry one rate per rank - a slow GPU
+    cannot hide behind the MAX-reduced time - and keep its cpu_baseline (rank 0 measures it after the barrier)."""
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2048", "--no-extra"],
+             env_extra={"AC3MI_BENCH_REHEARSE": "1", "AC3MI_BENCH_MILLION": "0"})
+    assert d["n_gpus"] == 2 and d["metric"] == json.load(open(os.path.join(H.ROOT, "BASELINE.json")))["metric"]
+    assert len(d["per_rank_frames_per_s"]) == 2 and all(x > 0 for x in d["per_rank_frames_per_s"])
+    assert abs(d["value"] - 2 * 2048 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["all_frames_ok"] and d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0
+    assert d["roofline"]["hbm"]["frac"] > 0
