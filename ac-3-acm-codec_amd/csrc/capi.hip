@@ -472,7 +472,7 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->decode_mode = 0;
     if (const char *e = getenv("AC3MI_DECODE_MODE")) {          // test aid: default front-end variant (ac3mi_set_decode_mode)
         const int m = atoi(e);
-        if (m >= 0 && m <= 5) ctx->decode_mode = m;
+        if (m >= 0 && m <= 5 && m != 2) ctx->decode_mode = m;
     }
     ctx->tile_frames = 131072;
     ctx->encode_mode = 0;
@@ -712,7 +712,7 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags)
 
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 5) return AC3MI_ERR_ARG;
+    if (!ctx || mode < 0 || mode > 5 || mode == 2) return AC3MI_ERR_ARG;       // (2: the one-kernel front end per frame, retired in round 4)
     ctx->decode_mode = mode;
     return AC3MI_OK;
 }
@@ -745,12 +745,12 @@ static int tile_streams(const ac3mi_ctx *ctx, int n_streams, int frames_per_stre
 static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
     if (frames_per_stream < 2) return false;
-    if (ctx->decode_mode) return ctx->decode_mode == 2 || ctx->decode_mode == 5;
+    if (ctx->decode_mode) return ctx->decode_mode == 5;
     return n_streams < 5120;
 }
 
 // split front end (parse kernel, then one wavefront per audio block: decode.hip MODE 4 / 5 + mant_kernel)?  auto: yes;
-// modes 1 / 2 force the one-kernel front ends, 4 / 5 the split one per stream / per frame.
+// mode 1 forces the one-kernel front end (one wavefront per stream), 4 / 5 the split one per stream / per frame.
 static bool use_split(const ac3mi_ctx *ctx)
 {
     return ctx->decode_mode == 0 || ctx->decode_mode >= 4;

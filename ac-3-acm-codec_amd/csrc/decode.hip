@@ -26,17 +26,12 @@ namespace ac3mi {
 
 // ---------------------------------------------------------------------------
 
-// MODE 0: one wavefront per stream, frames in order (the dither LFSR carries from frame to frame).
-// MODE 1 + lfsr_prefix_kernel + MODE 2: for few, long streams.  Nothing else carries across the frames of a valid
-// stream (block 0 re-sends exponents, coupling and bit-allocation parameters), so a counting pass (MODE 1: one
-// wavefront per frame, everything but the mantissa values) finds each frame's number of dither draws, a prefix pass
-// turns them into the LFSR state every frame starts from, and MODE 2 decodes all frames at once.
-// Wavefronts per SIMD the register budget is set for.  The stream-serial kernel (MODE 0) runs as fast with 4 (128 VGPRs,
-// 52 B of scratch) as with 5 (96 VGPRs, 160 B of scratch) on one-frame streams and 9 % faster on 8-frame streams (4.35 vs
-// 4.80 ms per 65 536 frames), and leaves a third of the spill traffic; the frame-parallel kernels are 3 % faster at 5.
-#ifndef DEC_LB
-#define DEC_LB 5
-#endif
+// MODE 0: one wavefront per stream, frames in order (the dither LFSR carries from frame to frame), everything in one
+// kernel: the front end of rounds 1-2, kept as the bit-identity reference of the tests and for A/B runs (ac3mi_set_decode_mode 1).
+// Nothing else carries across the frames of a valid stream (block 0 re-sends exponents, coupling and bit-allocation
+// parameters): the frame-parallel variant below (MODE 5) rests on that.
+// Wavefronts per SIMD the register budget is set for.  MODE 0 runs as fast with 4 (128 VGPRs, 52 B of scratch) as with 5
+// (96 VGPRs, 160 B of scratch) on one-frame streams and 9 % faster on 8-frame streams, and leaves a third of the spill traffic.
 #ifndef DEC_LB0
 #define DEC_LB0 4
 #endif
@@ -64,8 +59,9 @@ __device__ unsigned long long g_dec_cycles[8];
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC_LB) void decode_kernel(const DecodeParams P)
+__global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kernel(const DecodeParams P)
 {
+    static_assert(MODE == 0 || MODE == 4 || MODE == 5, "the one-kernel front ends per frame (1, 2) were retired in round 4");
     constexpr bool SERIAL = MODE == 0 || MODE == 4;         // one wavefront per stream, frames in order
     constexpr bool PARSE = MODE >= 4;                       // no mantissa values: block descriptors + rows for mant_kernel
     __shared__ DecLDS L;
@@ -114,8 +110,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
     st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
     DK_DECL();
-    st.lfsr = (MODE == 0 || MODE == 4) ? (uint32_t)P.lfsr_state[sslot]
-            : MODE == 2 ? (uint32_t)P.frame_lfsr[(size_t)s * P.frames_per_stream + f_first] : 1u;
+    st.lfsr = (MODE == 0 || MODE == 4) ? (uint32_t)P.lfsr_state[sslot] : 1u;
     int hth_fscod = -1;
     uint32_t frame_draws = 0;
     // MODE 4: the generator's position along its cycle instead of its state (k draws = k positions)
@@ -501,12 +496,12 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
                     B.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
                     const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
                     const bool lfsr_live = st.lfsr != 0;
-                    mant_block<MODE == 1>(B, [&](int slot) { return (const uint8_t *)L.exp + row_off(slot); },
+                    mant_block<false>(B, [&](int slot) { return (const uint8_t *)L.exp + row_off(slot); },
                                           [&](int slot) { return (const int8_t *)L.bap + row_off(slot); },
                                           [&](int c, int bnd) { return L.cplco[c][bnd]; }, L.cplbnd, L.desc, L.gcode, frw, FB.last,
                                           P.tab->qtab, P.lfsr_seq, lfsr_i0, lfsr_live, cblk, sb, lane);
                     // advance the dither generator past this block's draws
-                    if (MODE != 1 && lfsr_live && sb.draw) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)sb.draw) % 65535u];
+                    if (lfsr_live && sb.draw) st.lfsr = P.lfsr_seq[(lfsr_i0 + (uint32_t)sb.draw) % 65535u];
                 } else {
                     // parse only: the totals of every segment's row (cached per slot while row and range stay) give the bits and
                     // the dither draws of the block; rows that changed go to the workspace; the descriptor names them.
@@ -598,9 +593,14 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
             // ---- a failed block leaves zero planes ----
             if (err) { status |= 1u << blk; frame_dead = true; }
             if constexpr (PARSE) {
-                if ((err || !bd_ok) && lane == 0) reinterpret_cast<uint32_t *>(P.desc + (fidx * 6 + blk))[2] = 1u;      // flags: the block failed
+                if ((err || !bd_ok) && lane == 0) {
+                    reinterpret_cast<uint32_t *>(P.desc + (fidx * 6 + blk))[2] = 1u;      // flags: the block failed
+                    // (no descriptor was stored: the word a transcode's encoder reads as its search hint must not be a leftover
+                    // of an earlier call - 0 = no hint, see enc_search_kernel)
+                    P.desc[fidx * 6 + blk].src_snr = 0u;
+                }
             }
-            if (MODE != 1) {
+            {
                 if (err && !PARSE)
                     for (int c = 0; c < P.n_in; c++)
                         *reinterpret_cast<float4 *>(cblk + (size_t)c * 256 + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -611,9 +611,9 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
             __builtin_amdgcn_wave_barrier();
         }
         DK_LAP(5);
-        if (MODE != 1 && lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
-        if (MODE != 1 && lane == 0 && P.zs) P.zs[fidx] = (uint8_t)((status & 0x100u) ? 0 : surround_level_is_zero(st.acmod, st.output, st.slev));
-        if ((MODE == 1 || MODE == 5) && lane == 0) P.frame_draws[fidx] = frame_draws;
+        if (lane == 0) P.status[fidx] = status | (reuse0 ? 0x200u : 0u);
+        if (lane == 0 && P.zs) P.zs[fidx] = (uint8_t)((status & 0x100u) ? 0 : surround_level_is_zero(st.acmod, st.output, st.slev));
+        if (MODE == 5 && lane == 0) P.frame_draws[fidx] = frame_draws;
         if (MODE == 4) {
             if (lane == 0) P.frame_pos[fidx] = pos_live ? lfsr_pos : 0xffffffffu;
             lfsr_pos = (lfsr_pos + frame_draws) % 65535u;
@@ -622,13 +622,12 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : MODE == 0 ? DEC_LB0 : DEC
     if (MODE == 0 && lane == 0) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
     if (MODE == 4 && lane == 0 && pos_live) P.lfsr_state[sslot] = P.lfsr_seq[lfsr_pos];
     DK_END();
-    if (MODE == 2 && lane == 0 && f_end == P.frames_per_stream) P.lfsr_state[sslot] = (uint16_t)st.lfsr;
 }
 
 // LFSR state at the start of every frame: one thread per stream walks its frames' draw counts (the generator is
 // GF(2)-linear with period 65535: k draws = k positions along the cycle; state 0 is a fixed point).
 // frame_pos (split front end): the position along the cycle instead of the state (0xffffffff: state 0), and the stream's
-// final state written back here (MODE 2 does that itself).
+// final state written back here.
 __global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, uint32_t *frame_pos, uint16_t *lfsr_state, const int32_t *slot,
                                    const uint16_t *seq, const uint16_t *idx, int n_streams, int frames)
 {
@@ -841,15 +840,9 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
         hipLaunchKernelGGL(decode_kernel<0>, dim3(L.n_streams), dim3(64), fr_bytes, stream, P);
         return hipGetLastError();
     }
-    DecodeParams C = P;                                 // counting pass: no outputs but the draw counts
-    C.tap_exp = nullptr;
-    C.tap_bap = nullptr;
-    C.dyn_out = nullptr;
-    hipLaunchKernelGGL(decode_kernel<1>, dim3(units), dim3(64), fr_bytes, stream, C);
-    hipLaunchKernelGGL(lfsr_prefix_kernel, dim3((L.n_streams + 63) / 64), dim3(64), 0, stream, (const uint32_t *)L.frame_draws,
-                       L.frame_lfsr, (uint32_t *)nullptr, L.lfsr, L.slot, tab.lfsr_seq, tab.lfsr_idx, L.n_streams, L.frames_per_stream);
-    hipLaunchKernelGGL(decode_kernel<2>, dim3(units), dim3(64), fr_bytes, stream, P);
-    return hipGetLastError();
+    // (rounds 1-2 also had a one-kernel front end per FRAME for few long streams - counting pass, generator prefix, full pass;
+    // the split front end's per-frame parse kernel replaced it in round 3 and it was retired in round 4)
+    return hipErrorInvalidValue;
 }
 
 }  // namespace ac3mi

@@ -1255,12 +1255,12 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
             // rungs per sweep - the bounds above turn a rung that fails or fits by a margin into the verdict of every rung
             // beyond it.  (Which offsets are COSTED never changes a result: the reference's sequence is replayed from exact
             // verdicts only.)
-            if (n_cand == 0 && first_sweep && cold_hint && P.hint) {
+            const int hint0 = (first_sweep && cold_hint && P.hint) ? (int)__builtin_amdgcn_readfirstlane((int)P.hint[fidx * (size_t)P.hint_stride]) : 0;
+            if (n_cand == 0 && hint0 > 0) {                      // (0: the source frame's first block failed to parse - no hint)
                 // a transcode: decoded audio re-encoded at its source's rate lands within -5 .. +11 steps of the offsets the source
                 // frame carried: the first sweep costs around them - 3.4 -> 2.45 sweeps per frame (profiles/search_sim.py on
                 // second-generation content).  A hint far off (another target rate) costs a sweep; results never depend on it.
-                int g0 = (int)__builtin_amdgcn_readfirstlane((int)P.hint[fidx * (size_t)P.hint_stride]);
-                g0 = g0 < 8 ? 8 : g0 > 1000 ? 1000 : g0;
+                const int g0 = hint0 < 8 ? 8 : hint0 > 1000 ? 1000 : hint0;
                 add(g0 - 8); add(g0 + 2); add(g0 + 12);
             }
             if (n_cand == 0 && first_sweep && cold_hint) {

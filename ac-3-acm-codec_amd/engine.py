@@ -251,9 +251,8 @@ class Engine:
         self._check(self.lib.ac3mi_set_tile_frames(ctypes.c_void_p(self.ctx), int(frames)))
 
     def set_decode_mode(self, mode):
-        """0 = choose by batch shape, 1 = one wavefront per stream, 2 = one wavefront per frame, 3 = one workgroup per stream
-        with the transform fused in, 4 / 5 = parse kernel per stream / per frame + one wavefront per audio block
-        (ac3mi_set_decode_mode)."""
+        """0 = choose by batch shape, 1 = one wavefront per stream (one-kernel reference), 3 = one workgroup per stream with the
+        transform fused in, 4 / 5 = parse kernel per stream / per frame + one wavefront per audio block (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
     def set_encode_mode(self, mode):

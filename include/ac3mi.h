@@ -136,24 +136,26 @@ int ac3mi_set_state_slots(ac3mi_ctx *ctx, const int32_t *d_slots);
 int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
 
 /* How ac3mi_decode_batch / ac3mi_decode_s16_batch / ac3mi_transcode_batch spread the work over the GPU (new):
- *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame),
- *      coefficient planes go through HBM to the transform kernel;
- *   2  for few, long streams: a counting pass finds every frame's number of dither draws, a prefix pass the generator
- *      state each frame starts from, then one wavefront per frame decodes them all at once;
+ *   1  one wavefront per stream walks its frames in order (the dither generator's state carries from frame to frame) and
+ *      does everything up to the coefficient planes, which go through HBM to the transform kernel: the front end of
+ *      rounds 1-2, no longer chosen by 0 - kept as the reference the other variants are compared with bit for bit, and
+ *      for A/B runs;
  *   3  one 512-thread workgroup per stream: a wavefront per channel beside a parser and a transformer wavefront, the
  *      coefficient planes stay in LDS and the transform is fused in (a third of the latency of variant 1 per frame,
- *      no plane traffic in HBM; ahead for batches of up to about 700 streams);
+ *      no plane traffic in HBM; ahead for batches of up to 512 streams);
  *   4  the split front end, parse kernel per stream: one wavefront per stream parses side information, decodes
  *      exponents and allocates bits, frames in order, and only COUNTS each block's mantissas (from per-row totals); it
  *      leaves a descriptor per audio block plus the exponent / allocation rows that changed, and a second kernel unpacks
  *      and dequantises every block with a wavefront of its own (six per frame), before the transform kernel;
- *   5  the same with the parse kernel per frame and variant 2's prefix pass over the dither draws (few, long streams);
- *   0  (default) choose by batch shape: 3 for up to 512 streams of at most four frames, else 4 or 5.
+ *   5  the same with the parse kernel per FRAME and a prefix pass over the frames' dither draws (few, long streams);
+ *   0  (default) choose by batch shape: 3 for up to 512 streams of at most four frames, else 4, or 5 for fewer than 5 120
+ *      streams of more than one frame.
+ * (2, a one-kernel front end per frame, was retired in round 4: AC3MI_ERR_ARG.)
  * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
  * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and
  * the fused and the separate transform execute the same arithmetic.  A frame whose block 0 reuses state it did not send
  * (damaged or non-conforming) gets status bit AC3MI_STATUS_REUSE0 (0x200): variants 1, 3 and 4 then continue from what the
- * previous frame of the call left behind (as liba52 does), variants 2 and 5 from zeros - the result depends on the batch shape. */
+ * previous frame of the call left behind (as liba52 does), variant 5 from zeros - the result depends on the batch shape. */
 #define AC3MI_STATUS_REUSE0 0x200u
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode);
 

@@ -19,6 +19,10 @@
  *     rather than one inside each a52_block().  a52_dynrng(state, NULL, NULL) works as in liba52
  *   - after a52_block() has returned 1 for a block, the remaining blocks of that frame also return 1
  *     (liba52 would continue parsing from a corrupted position)
+ *   - samples: float PCM within 1e-6 RMS of liba52's, not bit-identical; at bias 384 / level 1 (what the MapTab
+ *     converters expect, src/AC3ACM.cpp:1555-1561) one float ulp is one 16-bit step, so converted s16 samples are within
+ *     ONE step of liba52's, never promised identical.  Exponents, bit allocation and dequantised coefficients are exact,
+ *     and AC3_encode_frame's bytes are exact for given samples
  */
 #ifndef AC3MI_DROPIN_H
 #define AC3MI_DROPIN_H

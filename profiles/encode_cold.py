@@ -15,6 +15,7 @@ pkg = bench.importlib_pkg()
 dev = torch.device("cuda:0")
 eng = pkg.Engine(0)
 MODE = int(os.environ.get("AC3MI_ENCODE_MODE", "0"))
+eng.set_encode_mode(MODE)
 enc = pkg.EncodeDesc(48000, 384000, 6)
 g = torch.Generator(device=dev).manual_seed(99)
 t = torch.arange(1536, device=dev, dtype=torch.float32)

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 pkg=bench.importlib_pkg(); eng=pkg.Engine(0)
 v=eng.probe_valu_rate(); s=eng.probe_salu_rate()

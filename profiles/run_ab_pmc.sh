@@ -6,7 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export AC3MI_NO_OVERLAP=1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/pmc -o m -- python3 $R/${SCRIPT:-profiles/decode_ab.py} "$@" > $OUT/pmc.log 2>&1
 python3 - <<PY
 import csv, collections

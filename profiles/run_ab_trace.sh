@@ -6,7 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export AC3MI_NO_OVERLAP=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/${SCRIPT:-profiles/decode_ab.py} "$@" > $OUT/trace.log 2>&1
 grep -E "mode|cold" $OUT/trace.log
 python3 - <<PY

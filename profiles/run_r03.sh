@@ -9,7 +9,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export AC3MI_NO_OVERLAP=1          # kernels back to back on one stream: one launch of a kernel = the whole batch
 export AC3MI_BENCH_MILLION=0           # its tiles would be the largest grids: per-frame counts are taken on the 65 536-frame legs
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-checks --no-warm --frames $FR"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B > $OUT/trace_bench.json 2> $OUT/trace.err

@@ -136,3 +136,21 @@ def test_secondary_liba52_exports_downmix_host_arithmetic():
             n = 1
         assert mask == int(coeff[5])
         assert np.array_equal(g[:n].view(np.uint32), coeff[:n].astype(np.float32).view(np.uint32))
+
+
+def test_maptab_has_the_reference_tables_holes():
+    """ConvertProc MapTab[2][6][6] (src/AC3ACM.cpp:87-90): [MMX ok][source channels - 1][destination channels - 1], NULL where
+    src/AC3ASM.asm:57-112 has a 0 - the driver tests an entry against NULL before it accepts a format pair
+    (src/AC3ACM.cpp:2017-2020), so the holes are part of the contract.  Per source row of the asm table: mono and stereo
+    destinations always (liba52 down- / upmixes), the source's own channel count from three channels on, nothing else; the
+    non-MMX and the MMX half have the same shape.  (Static data: no GPU needed.)"""
+    lib = H.pkg().load_library()
+    tab = (ctypes.c_void_p * 72).in_dll(lib, "MapTab")
+    rows = {0: (0, 1), 1: (0, 1), 2: (0, 1, 2), 3: (0, 1, 3), 4: (0, 1, 4), 5: (0, 1, 5)}       # AC3ASM.asm:60-84 / 88-112
+    for m in range(2):
+        for s_ in range(6):
+            for d in range(6):
+                entry = tab[(m * 6 + s_) * 6 + d]
+                assert (entry is not None) == (d in rows[s_]), (m, s_, d, entry)
+    lib.IsMMX.restype = ctypes.c_bool
+    assert lib.IsMMX() is True                      # AC3ASM.asm:199-204: the x64 build answers 1 unconditionally

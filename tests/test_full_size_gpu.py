@@ -156,3 +156,52 @@ def test_mixed_blocks_downmix_full_size(engine):
     got = tx[sl].cpu().numpy()
     assert H.rms(got.astype(np.float64) - ref) <= 1e-6
     assert np.abs(got - ref).max() <= 1e-5
+
+
+def test_million_stream_transcode_and_the_workspace_plan():
+    """BASELINE configs[4], one GPU's share: 2^20 independent one-frame streams decoded and re-encoded in ONE
+    ac3mi_transcode_batch call (eight tiles of 131 072 frames under the default workspace bound).  The batch is sixteen
+    replicas of 65 536 streams: every replica must come out byte-identical to the first whatever tile it fell in, every
+    status word clean, and the first replica's frames carry valid CRCs (hence all do).  On the way, the multi-GPU planner's
+    workspace figure (sharding.plan_transcode_bytes, which asks the library) against what a fresh engine really holds."""
+    import torch
+    import bench
+    pkg = H.pkg()
+    eng = pkg.Engine(0)                                   # a fresh context: its workspaces start empty
+    try:
+        enc = pkg.EncodeDesc(48000, 384000, 6)
+        fb = enc.frame_bytes()
+        pcm = _bench_pcm(seed=7)
+        last = torch.zeros((S, 6, 256), dtype=torch.int16, device="cuda")
+        csnr = torch.full((S,), 40, dtype=torch.int32, device="cuda")
+        base = eng.encode_batch(enc, pcm, CHMAP, last, csnr)
+        eng.sync()
+        del pcm, last, csnr
+        N = 1 << 20
+        big = base.repeat(N // S, 1, 1).contiguous()
+        dec = pkg.DecodeDesc(flags=7 | 16 | 32, level=1.0, bias=384.0, dynrng=1, acmod=7, lfeon=1, frame_bytes=fb)
+        delay = torch.zeros((N, 6, 128), dtype=torch.float32, device="cuda")
+        lfsr = torch.ones((N,), dtype=torch.int16, device="cuda")
+        last = torch.zeros((N, 6, 256), dtype=torch.int16, device="cuda")
+        csnr = torch.full((N,), 40, dtype=torch.int32, device="cuda")
+        status = torch.zeros((N, 1), dtype=torch.int32, device="cuda")
+        ws0 = eng.workspace_bytes()
+        out, _ = eng.transcode_batch(dec, enc, big, delay, lfsr, CHMAP, last, csnr, status=status)
+        eng.sync()
+        assert int((status & 0x3ff).max().item()) == 0
+        first = out[:S]
+        for r in range(1, N // S):
+            assert torch.equal(out[r * S:(r + 1) * S], first), "replica %d differs from replica 0" % r
+        assert torch.equal(csnr[S:2 * S], csnr[:S]) and torch.equal(lfsr[-S:], lfsr[:S])
+        host = first.cpu().numpy().reshape(S, -1)[:, :fb]
+        assert (host[:, 0] == 0x0b).all() and (host[:, 1] == 0x77).all()
+        assert bench.ac3_crc_ok(host) == 0
+        # the plan: the call went through in tiles of 131 072 frames, so the engine holds exactly one tile's workspaces
+        held = eng.workspace_bytes()
+        plan = pkg.sharding.plan_transcode_bytes(N)
+        assert plan["tile_frames"] == 131072 and ws0 < held <= plan["workspace"], (ws0, held, plan)
+        assert plan["workspace"] - held < 64 << 20            # (the encode call above left its own, smaller arrays)
+        free, total = torch.cuda.mem_get_info()
+        assert plan["total"] < total and plan["fits"]
+    finally:
+        eng.close()
