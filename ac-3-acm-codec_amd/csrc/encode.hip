@@ -94,6 +94,10 @@ struct alignas(16) SearchLDS {
     // the frame's run-start rows in (block, channel) order, for the search's sweeps: byte offset of the row's encoded
     // exponents (bits 0-13) | LFE row (7 coefficients, bit 14) | blocks the run covers (bits 16-21) | mask row (24-29)
     uint32_t rowdesc[36];
+    // per band of the row being costed (two buffers: the next row's are worked out a row ahead), for each candidate offset:
+    // 320 - max(0, ((mask - snroffset) >> 3) & ~3) as int16, so that a coefficient's table address x 4 is
+    // clamp(term - 16 exponent, 0, 252) - see lut_index
+    uint2 terms[2][50];
 };
 
 // put_bits (:148-176).  `v` may be wider than n bits (the release build does not mask it): the excess is OR-ed onto
@@ -1102,30 +1106,48 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
                 auto fetch = [&](uint32_t d) { return *reinterpret_cast<const uint32_t *>(ex + (d & 0x3fffu) + 4 * lane); };
                 uint32_t d0 = desc_of(0), d1 = desc_of(1), d2 = desc_of(2);
                 uint32_t ev = fetch(d0), ev1 = fetch(d1), ev2 = fetch(d2);
-                const pk2 so01 = {(short)so[0], (short)so[1]};
-                const pk2 so23 = {(short)so[2], (short)so[ENC_NC - 1]};
+                static_assert(ENC_NC == 3, "two packed candidates + one");
+                // a row's band terms (lane = band), a row ahead of its coefficients
+                auto terms = [&](uint32_t d, int buf) {
+                    const int m = L.mask[d >> 24][lane < 50 ? lane : 49];
+                    int D[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        int q = ((m - so[c]) >> 3) & ~3;
+                        q = q < 0 ? 0 : q;
+                        D[c] = 320 - q;
+                    }
+                    if (lane < 50) L.terms[buf][lane] = make_uint2((uint32_t)(D[0] & 0xffff) | ((uint32_t)D[1] << 16), (uint32_t)(D[2] & 0xffff));
+                };
+                terms(d0, 0);
+                // bins the row does not code: exponent 255 - term - 16 x 255 < 0, table address 0, bap 0, no bits
+                auto beyond = [&](int n) { const int k = n - 4 * lane; return k >= 4 ? 0u : k <= 0 ? 0xffffffffu : 0xffffffffu << (8 * k); };
+                const uint32_t um_fbw = beyond(nbc), um_lfe = beyond(7);
+                uint32_t boff[4];                                           // byte offsets of the lane's four bands in a terms buffer
+#pragma unroll
+                for (int j = 0; j < 4; j++) boff[j] = ((bandoff >> (8 * j)) & 0xffu) * 8u;
 #pragma unroll 1
                 for (int i = 0; i < nrows; i++) {
                     const uint32_t d3 = desc_of(i + 3);
                     const uint32_t ev3 = fetch(d3);
-                    const int n = (d0 & (1u << 14)) ? 7 : nbc;
-                    const int16_t *Mr = &L.mask[d0 >> 24][0];
+                    if (i + 1 < nrows) terms(d1, (i + 1) & 1);
+                    const char *Tr = reinterpret_cast<const char *>(&L.terms[i & 1][0]);
+                    const uint32_t em = ev | ((d0 & (1u << 14)) ? um_lfe : um_fbw);
                     uint32_t sum[ENC_NC];
 #pragma unroll
                     for (int c = 0; c < ENC_NC; c++) sum[c] = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int e = (ev >> (8 * j)) & 0xff, m = Mr[(bandoff >> (8 * j)) & 0xff];
-                        const int d4 = 4 * lane + j < n ? 320 - 16 * e : -16384;
-                        const pk2 a01 = lut_index2(d4, m, so01);
-                        sum[0] += L.bitlut[(uint16_t)a01.x >> 2];
-                        sum[1] += L.bitlut[(uint16_t)a01.y >> 2];
-                        if (ENC_NC == 3) sum[2] += L.bitlut[lut_index(d4, m, so[2])];
-                        else {
-                            const pk2 a23 = lut_index2(d4, m, so23);
-                            sum[2] += L.bitlut[(uint16_t)a23.x >> 2];
-                            sum[ENC_NC - 1] += L.bitlut[(uint16_t)a23.y >> 2];
-                        }
+                        const uint32_t e16 = __umul24((em >> (8 * j)) & 0xffu, 0x00100010u);           // 16 x exponent, twice
+                        const uint2 t = *reinterpret_cast<const uint2 *>(Tr + boff[j]);
+                        pk2 a01 = __builtin_bit_cast(pk2, t.x) - __builtin_bit_cast(pk2, e16);
+                        pk2 a2 = __builtin_bit_cast(pk2, t.y) - __builtin_bit_cast(pk2, e16);
+                        a01 = __builtin_elementwise_min(__builtin_elementwise_max(a01, (pk2){0, 0}), (pk2){252, 252});
+                        a2 = __builtin_elementwise_min(__builtin_elementwise_max(a2, (pk2){0, 0}), (pk2){252, 252});
+                        const char *lut = reinterpret_cast<const char *>(&L.bitlut[0]);
+                        sum[0] += *reinterpret_cast<const uint32_t *>(lut + (uint16_t)a01.x);
+                        sum[1] += *reinterpret_cast<const uint32_t *>(lut + (uint16_t)a01.y);
+                        sum[2] += *reinterpret_cast<const uint32_t *>(lut + (uint16_t)a2.x);
                     }
 #pragma unroll
                     for (int B = 0; B < 6; B++) {
@@ -1372,10 +1394,7 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
     extern __shared__ uint4 pk_dyn[];
     uint32_t *fr = reinterpret_cast<uint32_t *>(pk_dyn);
     const int lane = threadIdx.x;
-    const size_t fidx = blockIdx.x;
     PK_DECL();
-    PK_T0();
-    PK_COUNT(7);
 
     // (byte loop kept: copying the table as dwords measured 4 % SLOWER in round 3 - code placement, not work)
     for (int i = lane; i < 256; i += 64) L.crc_tab[i] = P.tab->crc_tab[i];
@@ -1383,15 +1402,22 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
         const int bp = P.tab->baptab[lane];
         L.packlut[lane] = mant_pack_word(bp, plain_bits(bp));
     }
-    for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
     mant_lists_init(L.glist, lane);
-
+    const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&P.tab->band_of_bin[4 * lane]);     // bands of bins 4*lane..+3
     // fixed allocation codes (:861-879)
     constexpr int sdecaycod = 2, fdecaycod = 1, sgaincod = 1, dbkneecod = 2, floorcod = 4, fgaincod = 4;
     const int nch = FIXED51 ? 6 : P.nch, nfbw = FIXED51 ? 5 : P.nfbw, nbc = FIXED51 ? 223 : P.nbc;
     const int acmod = FIXED51 ? 7 : P.acmod;
     const bool lfe = FIXED51 ? true : P.lfe != 0;
     const int fs = P.frame_words;
+    // (One wavefront per frame, on purpose.  A persistent grid - 16 wavefronts per CU walking the frames, tables set up once per
+    // wavefront - was measured in round 4: 2.06 ms per 65 536 frames against 1.76; with the loop but one frame per wavefront
+    // 1.84.  Wavefronts that start together stay in step - all in their scalar side information, then all in their mantissa
+    // passes - and the units they share are used in turns instead of side by side; the dispatcher's staggered starts mix the phases.)
+    const size_t fidx = blockIdx.x;
+    PK_T0();
+    PK_COUNT(7);
+    for (int i = lane; i < P.frw / 4; i += 64) reinterpret_cast<uint4 *>(fr)[i] = make_uint4(0, 0, 0, 0);
     const int32_t *md = P.mdct + fidx * 6 * nch * 256;
     const uint8_t *ex = P.eexp + fidx * 6 * nch * 256;
     // lane 6 b + ch: exponent strategy and exp_samples of channel ch in block b
@@ -1408,7 +1434,6 @@ __global__ __launch_bounds__(64, ENC_PACK2_LB) void enc_packf_kernel(const PackP
         snroffset = (((csnr - 15) << 4) + fsnr) << 2;
         if (w1 & 0x100) snroffset = (((w1 >> 9) - 15) << 4) << 2;       // a frame whose search failed: the last attempt's allocation under the stale header offsets
     }
-    const uint32_t bandoff = *reinterpret_cast<const uint32_t *>(&P.tab->band_of_bin[4 * lane]);     // bands of bins 4*lane..+3
     WAVE_SYNC();
     PK_LAP(6);
 
