@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of profiles/run_r03.sh (run_r02.sh) into the summaries committed under profiles/:
+"""Turns the rocprofv3 outputs of profiles/run_r04.sh (run_r03.sh, run_r02.sh) into the summaries committed under profiles/:
    <tag>_kernel_stats.csv      per-kernel durations (kernel trace of the whole bench, secondary legs included)
    <tag>_hbm_traffic.json      per kernel: FETCH_SIZE (doubled, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE per launch vs the
                                algorithmic bytes of SURVEY.md 8(d)
@@ -71,6 +71,8 @@ ALG = {
     "enc_mdct_kernel": 18432 + 6144,
     "enc_pack_kernel<0>": 1536,
     "enc_pack_kernel<2>": 1536,
+    "enc_packf_kernel<true>": 1536,
+    "enc_packf_kernel<false>": 1536,
     "enc_packb_kernel": 1536,
 }
 fetch = per_kernel("pmc_fetch/*counter_collection.csv", {"FETCH_SIZE"})
@@ -115,7 +117,7 @@ def pick(*prefixes):
 legs = {
     "decode": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
     "decode_s16": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
-    "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>", "enc_pack_kernel<1>", "enc_pack_kernel<2>", "enc_packb_kernel"),
+    "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>", "enc_pack_kernel<1>", "enc_pack_kernel<2>", "enc_search_kernel<1>", "enc_packf_kernel", "enc_packb_kernel"),
     "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>", "xform_kernel<true, 3, false>"),
 }
 legs["transcode"] = sorted(set(legs["decode_s16"]) | set(legs["encode"]))
