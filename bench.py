@@ -777,16 +777,20 @@ def main():
     issue = rl.get("issue")
     roofline = {
         "bound": "issue",
-        "achieved": (rl["valu_issue"]["achieved"] + rl["salu_issue"]["achieved"]) if issue else None,
-        "peak": (rl["valu_issue"]["peak"]) if issue else None,
+        "achieved": rl["valu_issue"]["achieved"] if issue else None,
+        "peak": rl["valu_issue"]["peak"] if issue else None,
         "unit": "Ginst/s",
-        "frac": issue["frac"] if issue else None,
+        "frac": rl["valu_issue"]["frac"] if issue else None,
         "traffic": traffic,
-        "note": "decode + encode is bound by instruction issue, not by HBM (hbm.frac): frac = share of the chip's vector issue slots the "
-                "call's vector instructions need at its measured rate + the same for the scalar unit (committed per-frame counts x this "
-                "run's rate / this run's probe ceilings); `achieved` = vector + scalar instructions per second, `peak` = the vector probe",
+        "note": "decode + encode is bound by instruction issue, not by HBM (hbm.frac).  achieved / peak / frac = the VECTOR unit, the binding "
+                "one: the call's vector instructions per second (committed per-frame counts x this run's rate) against "
+                "ac3mi_probe_valu_rate of this run x 1 024 SIMDs (8 wavefronts per SIMD issuing nothing else; the kernels run 4 - 8 per SIMD with "
+                "a scalar stream beside, where the vector stream tops out at 0.75 - 0.89 of that: extra.mixed_probe).  issue.salu = the same "
+                "for the CUs' scalar units, issue.sum = both shares added (they are different units and overlap across wavefronts: it can "
+                "exceed 1)",
         "hbm": hbm,
-        "issue": {"valu": rl.get("valu_issue"), "salu": rl.get("salu_issue"), "frac": issue["frac"] if issue else None},
+        "issue": {"valu": rl.get("valu_issue"), "salu": rl.get("salu_issue"), "frac": rl["valu_issue"]["frac"] if issue else None,
+                  "sum": issue["frac"] if issue else None},
         "kernels": tc_kernels,
         "call_ms": call_ms,
         "valu_probe_ginst_per_s_per_simd": rate,
