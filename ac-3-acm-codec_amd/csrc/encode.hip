@@ -1,22 +1,19 @@
-// encode.hip — AC-3 encoder on gfx950, bit-exact restatement of ENC/ac3enc.cpp
-// (AC3_encode_frame, :1640-1763) in two kernels.
+// encode.hip — AC-3 encoder on gfx950, bit-exact restatement of ENC/ac3enc.cpp (AC3_encode_frame, :1640-1763).
 //
-//  enc_mdct_kernel   one wavefront per (stream, frame, channel): gather/deinterleave via chmap,
-//                    Q15 window, block-floating-point normalisation, the reference's 16-bit
-//                    radix-2 DIT FFT (one butterfly per lane per pass, data in LDS so that every
-//                    butterfly has exactly the reference's operands, shifts and int16 stores),
-//                    post-rotation, exponent extraction             [ac3enc.cpp:1665-1722, 462-603];
-//                    then, still per channel (exp_stage): exponent strategy, min-merge over
-//                    reuse runs, the +-2 constraint in closed form (min over j of g[j] + 2|i-j| as a
-//                    prefix and a suffix minimum), band PSDs and masking curves of the blocks that
-//                    send exponents.                                          [ac3enc.cpp:606-761, 220-367]
-//  enc_pack_kernel   one wavefront per stream, frames in order (the SNR-offset search starts from
-//                    the previous frame's csnroffst): the reference's exact search sequence with
-//                    memoised verdicts and up to three offsets costed per sweep (one LUT read per
-//                    coefficient and offset, every run of exponent reuse counted once), quantisation,
-//                    grouped-mantissa assembly with LDS atomics, bit packing with prefix-summed
-//                    offsets, both CRCs by per-lane chunk CRC + GF(2) combine.
-//                                                                      [ac3enc.cpp:764-975, 1113-1638]
+//  enc_mdct_kernel     one wavefront per (stream, frame, channel): gather/deinterleave via chmap, Q15 window,
+//                      block-floating-point normalisation, the reference's 16-bit radix-2 DIT FFT in registers (one
+//                      butterfly per lane and pass with exactly the reference's operands, shifts and int16
+//                      truncations; lanes trade one point per pass), post-rotation, exponent extraction
+//                      [ac3enc.cpp:1665-1722, 462-603]; then, still per channel (exp_stage): exponent strategy,
+//                      min-merge over reuse runs, the +-2 constraint in closed form, band PSDs and masking curves of
+//                      the blocks that send exponents                                   [ac3enc.cpp:606-761, 220-367]
+//  enc_search_kernel   <1>: one wavefront per stream, frames in order (the SNR-offset search starts from the previous
+//                      frame's csnroffst): the reference's exact search sequence replayed from exact verdicts, three
+//                      offsets costed per sweep over the frame's run-start rows; <3>: one wavefront per frame
+//                      tabulates verdicts for few long streams                          [ac3enc.cpp:764-975]
+//  enc_packf_kernel    one wavefront per frame packs it: header, side information, exponent groups, the mantissas
+//                      (enc_mant.h), both CRCs by per-lane chunk CRC + GF(2) combine    [ac3enc.cpp:1113-1638]
+//  enc_packb_kernel    the same with a workgroup of six wavefronts per frame, one per audio block (small batches)
 //
 // Integer arithmetic only (no -ffast-math dependence); the Q15 tables come from the host (capi.hip)
 // with the reference's expressions.
@@ -36,7 +33,6 @@ namespace ac3mi {
 
 __device__ __forceinline__ int ilog2u(unsigned v) { return v ? 31 - __builtin_clz(v) : 0; }   // av_log2, :1539-1567
 
-__device__ __forceinline__ int wave_or(int v) { return (int)wave_or_u32((uint32_t)v); }
 __device__ __forceinline__ int wave_sum(int v) { return (int)wave_sum_u32((uint32_t)v); }
 
 // ---------------------------------------------------------------------------------------------
@@ -88,7 +84,7 @@ struct MaskTabs {
 // The search kernel's LDS: the frame's 36 masking curves, the cost table and the list of run-start rows.
 struct alignas(16) SearchLDS {
     int16_t mask[36][50];       // masking curve minus the floor, row blk * nch + ch as exp_stage leaves them (a straight copy)
-    uint32_t bitlut[64];        // see lut_index
+    uint32_t bitlut[64];        // see "bap of one coefficient" below
     uint8_t strat[6][6];
     uint8_t band_of_bin[256];
     // the frame's run-start rows in (block, channel) order, for the search's sweeps: byte offset of the row's encoded
@@ -96,7 +92,7 @@ struct alignas(16) SearchLDS {
     uint32_t rowdesc[36];
     // per band of the row being costed (two buffers: the next row's are worked out a row ahead), for each candidate offset:
     // 320 - max(0, ((mask - snroffset) >> 3) & ~3) as int16, so that a coefficient's table address x 4 is
-    // clamp(term - 16 exponent, 0, 252) - see lut_index
+    // clamp(term - 16 exponent, 0, 252)
     uint2 terms[2][50];
 };
 
@@ -113,158 +109,8 @@ __device__ __forceinline__ void put_bits(uint32_t *fr, int frw, uint32_t pos, in
     if (lo) atomicOr(&fr[w + 1], lo);
 }
 
-__device__ __forceinline__ int lowcomp_step(int a, int b0, int b1, int bin)     // :183-215
-{
-    if (bin < 7) {
-        if (b0 + 256 == b1) a = 384;
-        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
-    } else if (bin < 20) {
-        if (b0 + 256 == b1) a = 320;
-        else if (b0 > b1) { a -= 64; if (a < 0) a = 0; }
-    } else {
-        a -= 128; if (a < 0) a = 0;
-    }
-    return a;
-}
-
-// PSD integration, excitation and mask for one (block, channel) - run by ONE lane, in place in its LDS row:
-// first the band PSDs are written to mask[], then one forward walk turns them into the masking curve
-// (band b only needs bndpsd[b] and bndpsd[b+1], both still intact when b is overwritten).   :220-367
-__device__ void compute_mask_lane(const MaskTabs &L, const uint8_t *exp, int end, bool is_lfe, int16_t *mask,
-                                  int sdecay, int fdecay, int sgain, int dbknee, int fgain, int halfrate)
-{
-    int j = 0, k = 0, v, lowcomp = 0, fast = 0, slow = 0, begin, end1, bin;
-    auto logadd = [&](int a, int pj) {
-        const int c = a - pj;
-        int t = (c >= 0 ? c : -c) >> 1;
-        t = t > 255 ? 255 : t;
-        return (c >= 0 ? a : pj) + (int)L.latab[t];
-    };
-    // bands 0..27 are one bin wide
-    const int nsingle = end < 28 ? end : 28;
-#pragma unroll 4
-    for (; k < nsingle; k++) mask[k] = (int16_t)(3072 - ((int)(int8_t)exp[k] << 7));
-    j = k;
-    // wider bands (3, 6, 12, 24 bins): three exponents per step, so their LDS reads are independent
-    while (j < end) {
-        end1 = L.band_start[k + 1] < end ? L.band_start[k + 1] : end;
-        v = 3072 - ((int)(int8_t)exp[j] << 7);
-        j++;
-        if (j + 2 <= end1) {
-            const int p1 = 3072 - ((int)(int8_t)exp[j] << 7), p2 = 3072 - ((int)(int8_t)exp[j + 1] << 7);
-            v = logadd(logadd(v, p1), p2);
-            j += 2;
-        }
-        for (; j + 3 <= end1; j += 3) {
-            const int p0 = 3072 - ((int)(int8_t)exp[j] << 7), p1 = 3072 - ((int)(int8_t)exp[j + 1] << 7);
-            const int p2 = 3072 - ((int)(int8_t)exp[j + 2] << 7);
-            v = logadd(logadd(logadd(v, p0), p1), p2);
-        }
-        for (; j < end1; j++) v = logadd(v, 3072 - ((int)(int8_t)exp[j] << 7));
-        mask[k++] = (int16_t)v;
-    }
-
-    const int bndend = L.band_of_bin[end - 1] + 1;
-    auto finish = [&](int b, int excite, int psd) {                  // masking curve :357-367
-        int v1 = excite;
-        const int t = dbknee - psd;
-        if (t > 0) v1 += t >> 2;
-        const int h = L.hth[b >> halfrate];
-        mask[b] = (int16_t)(v1 > h ? v1 : h);
-    };
-    int p0 = mask[0], p1 = mask[1], p2 = bndend > 2 ? mask[2] : 0;
-    lowcomp = lowcomp_step(lowcomp, p0, p1, 0);
-    const int e0 = (int16_t)(p0 - fgain - lowcomp);
-    lowcomp = lowcomp_step(lowcomp, p1, p2, 1);
-    const int e1 = (int16_t)(p1 - fgain - lowcomp);
-    finish(0, e0, p0);
-    finish(1, e1, p1);
-    begin = 7;
-    int cur = p2;                                                   // bndpsd[bin]
-    for (bin = 2; bin < 7; bin++) {
-        const int nxt = (is_lfe && bin == 6) ? 0 : mask[bin + 1];   // bndpsd[bin+1]
-        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, cur, nxt, bin);
-        fast = cur - fgain;
-        slow = cur - sgain;
-        finish(bin, (int16_t)(fast - lowcomp), cur);
-        const bool stop = !(is_lfe && bin == 6) && cur <= nxt;
-        cur = nxt;
-        if (stop) { begin = bin + 1; break; }
-    }
-    end1 = bndend > 22 ? 22 : bndend;
-    for (bin = begin; bin < end1; bin++) {
-        const int nxt = (is_lfe && bin == 6) ? 0 : mask[bin + 1];
-        if (!(is_lfe && bin == 6)) lowcomp = lowcomp_step(lowcomp, cur, nxt, bin);
-        fast -= fdecay; v = cur - fgain; if (fast < v) fast = v;
-        slow -= sdecay; v = cur - sgain; if (slow < v) slow = v;
-        v = fast - lowcomp; if (slow > v) v = slow;
-        finish(bin, (int16_t)v, cur);
-        cur = nxt;
-    }
-    for (bin = 22; bin < bndend; bin++) {
-        cur = mask[bin];
-        fast -= fdecay; v = cur - fgain; if (fast < v) fast = v;
-        slow -= sdecay; v = cur - sgain; if (slow < v) slow = v;
-        finish(bin, (int16_t)(fast > slow ? fast : slow), cur);
-    }
-    for (bin = bndend; bin < 50; bin++) mask[bin] = 0;
-}
-
-// constrain_exponents = encode_exp (:684-761), in place on one 256-byte row, run by ONE lane.
-// (nb_groups counts exponent entries after grouping: up to 222 for D15.)
-// The +-2 delta constraint has the closed form min over j of g[j] + 2|i-j|: one ascending sweep (fused with
-// the group minima) and one descending sweep (fused with the expansion back to bins).  Both sweeps carry
-// the neighbour in a register and move 8 entries per step, so the LDS reads of a step are independent.
-__device__ int encode_exp_lane(uint8_t *row, int n, int strategy)
-{
-    const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
-    const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
-    int prev = row[0] > 15 ? 15 : row[0];
-    row[0] = (uint8_t)prev;
-    // ascending: entry i = min of bins 1+(i-1)gs .. +gs-1, then <= previous entry + 2.  Reads run ahead of
-    // writes (bin index >= entry index).
-    for (int i0 = 1; i0 <= ng; i0 += 8) {
-        int m[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + u < ng ? i0 + u : ng;
-            const int k = 1 + (i - 1) * gs;
-            int x = row[k];
-            if (gs >= 2) { const int y = row[k + 1]; x = y < x ? y : x; }
-            if (gs == 4) { const int y = row[k + 2], z = row[k + 3]; x = y < x ? y : x; x = z < x ? z : x; }
-            m[u] = x;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (i0 + u > ng) break;
-            prev = m[u] < prev + 2 ? m[u] : prev + 2;
-            row[i0 + u] = (uint8_t)prev;
-        }
-    }
-    // descending: entry i <= next entry + 2, then copied to its gs bins (writes stay at or above the entry
-    // index, and above every entry a later step still has to read)
-    int next = row[ng];
-    for (int i0 = ng; i0 >= 1; i0 -= 8) {
-        int m[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) m[u] = row[i0 - u >= 1 ? i0 - u : 1];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 - u;
-            if (i < 1) break;
-            if (i < ng) next = m[u] < next + 2 ? m[u] : next + 2;
-            const int k = 1 + (i - 1) * gs;
-            row[k] = (uint8_t)next;
-            if (gs >= 2) row[k + 1] = (uint8_t)next;
-            if (gs == 4) { row[k + 2] = (uint8_t)next; row[k + 3] = (uint8_t)next; }
-        }
-    }
-    if (row[0] > next + 2 && ng >= 1) row[0] = (uint8_t)(row[1] + 2);
-    return 4 + (ng / 3) * 7;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Wavefront-wide versions of the two routines above for exp_stage (same results).
+// exp_stage's routines, wavefront-wide.
 
 // per byte (values < 128): b's byte where it is smaller and `where` selects the byte, else a's
 __device__ __forceinline__ uint32_t bytes_min_where(uint32_t a, uint32_t b, uint32_t where)
@@ -802,35 +648,12 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
 // bap of one coefficient for SNR offset `snroffset` (:393-420):
 //   v = ((max(mask - snroffset - floor, 0)) & 0x1fe0) + floor,  address = (psd - v) >> 5,  psd = 3072 - 128 exp
 //   =>  address = clamp(80 - 4 exp - max(0, (mask - floor - snroffset) >> 5), 0, 63)       (floor = 0x1f0)
+// The search kernel works on 4 x address (a byte offset into bitlut): clamp(term - 16 exp, 0, 252) with the band's
+// term = 320 - max(0, ((mask - floor - snroffset) >> 3) & ~3) (SearchLDS::terms); the packers on the address itself (enc_mant.h).
 // L.bitlut[address] = plain mantissa width | (bap==1) << 9 | (bap==2) << 14 | (bap==4) << 19: 24 bits, so that a lane's sums
 // over a frame's rows (width <= 6 x 4 x 16 = 384, counts <= 24) stay clear of each other and a sum can be added to a block's
 // account with one v_mad_u32_u24.
-// lut_index returns the address with d4 = 4 * (80 - 4 exp) (hugely negative for a padding item: address 0,
-// bap 0, no bits).
-
-__device__ __forceinline__ int lut_index(int d4, int mask_minus_floor, int snroffset)
-{
-    int q4 = ((mask_minus_floor - snroffset) >> 3) & ~3;
-    q4 = q4 < 0 ? 0 : q4;
-    int a4 = d4 - q4;
-    a4 = a4 < 0 ? 0 : a4 > 252 ? 252 : a4;
-    return a4 >> 2;
-}
-
-// two offsets at once in packed 16-bit arithmetic (every quantity of lut_index fits 16 bits: masks and offsets are below
-// 2^13 in magnitude, d4 of a padding item is -16384 here): returns the two addresses * 4 = byte offsets into bitlut
 typedef short pk2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk2 lut_index2(int d4, int mask_minus_floor, pk2 snroffsets)
-{
-    const pk2 mm = {(short)mask_minus_floor, (short)mask_minus_floor}, dd = {(short)d4, (short)d4};
-    pk2 q = (mm - snroffsets) >> 3;
-    q &= (pk2){(short)~3, (short)~3};
-    q = __builtin_elementwise_max(q, (pk2){0, 0});
-    pk2 a = dd - q;
-    a = __builtin_elementwise_max(a, (pk2){0, 0});
-    a = __builtin_elementwise_min(a, (pk2){252, 252});
-    return a;
-}
 
 // plain (ungrouped) mantissa width of a bap code; 0 for the grouped codes 1, 2, 4 and for 0
 __device__ __forceinline__ int plain_bits(int bp)
@@ -864,19 +687,6 @@ struct SnrSearch {
         else if (phase == 4) { if (ok) fsnr += 1; else phase = 5; }
     }
 };
-
-__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)        // :1513-1524, poly 0x18005
-{
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (a & 1) c ^= b;
-        a >>= 1;
-        b <<= 1;
-        if (b & 0x10000u) b ^= 0x18005u;
-    }
-    return c;
-}
 
 // CRC-16 of `len` bytes ending at byte `end` (exclusive) of the MSB-first frame, per-lane chunks of C
 // bytes aligned to the end of the region, combined in GF(2)[x]/poly.  Bytes < zero_below count as 0.
