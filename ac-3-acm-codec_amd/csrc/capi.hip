@@ -744,8 +744,8 @@ static int tile_streams(const ac3mi_ctx *ctx, int n_streams, int frames_per_stre
 // the chip with one wavefront each: 256 CUs x 20 wavefronts)
 static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_per_stream)
 {
+    if (ctx->decode_mode) return ctx->decode_mode == 5;            // (forced: also for one-frame streams, A/B runs)
     if (frames_per_stream < 2) return false;
-    if (ctx->decode_mode) return ctx->decode_mode == 5;
     return n_streams < 5120;
 }
 
