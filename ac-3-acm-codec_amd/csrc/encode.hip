@@ -867,13 +867,15 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
             f_cc = (int)word(6);
         }
         bool went_down = false, went_up = false;
-        // Verdicts that follow from a costed offset WITHOUT costing: the frame's mantissa bits are (sum over coefficients of a
-        // nominal width: 0, 5/3, 7/3, 3, 7/2, 4, 5 ... 16 by bap) + (what the grouped codes' ceilings add: < 5 2/3 + 7 2/3 +
-        // 7 1/2 = 11.5 bits per block, < 69 per frame).  The nominal sum cannot fall when the offset rises (a coefficient's
-        // bap table address, :393-420, never falls with snroffset, and the widths rise with the address), so an offset that
-        // fails by more than 69 bits proves every higher one fails, and one that fits with more than 69 to spare proves every
-        // lower one fits - exactly, whatever the ceilings do.  Offsets as g = 16 csnroffst + fsnroffst.
-        constexpr int MARGIN = 72;
+        // Verdicts that follow from a costed offset WITHOUT costing.  A frame's mantissa bits are N + E: N = the sum over the
+        // coefficients of a nominal width (0, 5/3, 7/3, 3, 7/2, 4, 5 ... 16 by bap), E = what the grouped codes' ceilings add - per
+        // block 10/3 or 5/3 bits for one or two 3-level mantissas left over, 14/3 or 7/3 for 5-level ones, 7/2 for an odd 11-level
+        // one: 0 <= E <= 69 bits a frame.  N cannot fall when the offset rises (a coefficient's bap table address, :393-420, never
+        // falls with snroffset, and the widths rise with the address).  So with the E of a COSTED offset g1 in hand (it follows from
+        // the counts the sweep reduces anyway): every g > g1 spends at least N(g1) = bits(g1) - E(g1): all fail if spare(g1) <
+        // -E(g1); every g < g1 spends at most N(g1) + 69: all fit if spare(g1) >= 69 - E(g1) - exactly, whatever their own ceilings
+        // do.  (Rounds 2-3 used +-72 for both; the band of undecided offsets is half as wide now: profiles/search_sim.py, 3.39 ->
+        // 3.22 sweeps per fresh frame, 2.57 -> 2.33 with a transcode's hint.)  Sixths of a bit; offsets as g = 16 csnroffst + fsnroffst.
         int fit_hi = -1, fail_lo = 1 << 20;
         // Every offset costed for this frame, whether the reference asks for it or not: 1024-bit maps "costed" / "fits", word w in
         // lane w of one register each; and the two costed offsets that enclose the boundary most closely, with their spare bits.
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
             // of a (block, candidate) pair: three 10-bit fields reduced over either half of the wavefront (32 x 24 < 1024) and
             // dropped into lane 8 c + B of two collecting registers, so that the ceilings (:1194-1238: a code per 3, 3 or 2
             // mantissas of a block) are worked out once, across lanes, instead of pair by pair on the scalar unit.
-            int total[ENC_NC];
+            int total[ENC_NC], extra6[ENC_NC];
             {
                 uint32_t col_lo = 0, col_hi = 0, bits_l[ENC_NC];
 #pragma unroll
@@ -1000,12 +1002,17 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
                 const uint32_t n1 = (col_lo & 1023u) + (col_hi & 1023u), n2 = ((col_lo >> 10) & 1023u) + ((col_hi >> 10) & 1023u);
                 const uint32_t n4 = (col_lo >> 20) + (col_hi >> 20);
                 uint32_t t = 5u * (((n1 + 2u) * 0xaaabu) >> 17) + 7u * (((n2 + 2u) * 0xaaabu) >> 17) + 7u * ((n4 + 1u) >> 1);
+                // ... and the ceilings' share of them in sixths of a bit (<= 69 per block): bits << 10 | sixths ride one reduction
+                t = (t << 10) | (6u * t - (10u * n1 + 14u * n2 + 21u * n4));
                 t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xf, 0xf, true);      // lanes 8 c .. 8 c + 7 -> lane 8 c + 7
                 t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xf, 0xf, true);
                 t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, true);
 #pragma unroll
-                for (int c = 0; c < ENC_NC; c++)
-                    total[c] = (int)wave_sum_u32(bits_l[c]) + __builtin_amdgcn_readlane((int)t, 8 * c + 7);
+                for (int c = 0; c < ENC_NC; c++) {
+                    const uint32_t tc = (uint32_t)__builtin_amdgcn_readlane((int)t, 8 * c + 7);
+                    total[c] = (int)wave_sum_u32(bits_l[c]) + (int)(tc >> 10);
+                    extra6[c] = (int)(tc & 1023u);
+                }
             }
 #pragma unroll
             for (int i = 0; i < ENC_NC; i++) {
@@ -1013,8 +1020,8 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
                 const int spare = budget - total[i];
                 const bool ok = spare >= 0;
                 const int g = cg[i], cand_ci = g >> 4, cand_fi = g & 15;
-                if (spare >= MARGIN && g > fit_hi) fit_hi = g;
-                if (spare <= -MARGIN && g < fail_lo) fail_lo = g;
+                if (6 * spare >= 414 - extra6[i] && g > fit_hi) fit_hi = g;
+                if (6 * spare < -extra6[i] && g < fail_lo) fail_lo = g;
                 {
                     const uint32_t bit = lane == (g >> 5) ? 1u << (g & 31) : 0u;
                     costed_map |= bit;

@@ -448,23 +448,31 @@ static int alloc_and_count(const int16_t *psd, const int16_t *mask, int end, int
     return bits;
 }
 
+static int last_extra6;         /* measurement aid, see orc_ac3enc_set_spare_curve */
 static int try_offsets(orc_ac3enc_t *s, uint8_t bap[NBLK][MAXCH][256], int frame_bits, int floorv,
                        int csnr, int fsnr)
 {
     int snroffset = (((csnr - 15) << 4) + fsnr) << 2, b, ch;
+    static const int x1[3] = { 0, 20, 10 }, x2[3] = { 0, 28, 14 }, x4[2] = { 0, 21 };
+    last_extra6 = 0;
     for (b = 0; b < NBLK; b++) {
         int cnt[3] = { 0, 0, 0 };
         for (ch = 0; ch < s->nch_all; ch++)
             frame_bits += alloc_and_count(s->psd[b][ch], s->mask[b][ch], s->nb_coefs[ch], snroffset,
                                           floorv, bap[b][ch], cnt);
+        /* what the block's unfinished groups cost beyond their members' nominal 5/3, 7/3 and 7/2 bits, in sixths of a bit */
+        last_extra6 += x1[cnt[0]] + x2[cnt[1]] + x4[cnt[2]];
     }
     return 16 * s->frame_words - frame_bits;
 }
 
 /* measurement aid (profiles/search_sim.py: how many offsets a search policy has to cost): when set, every search
    first tabulates the spare bits of its frame at all 1024 offsets g = 16 csnroffst + fsnroffst */
-static int *spare_curve;
+static int *spare_curve, *extra_curve;
 void orc_ac3enc_set_spare_curve(int *dst1024) { spare_curve = dst1024; }
+/* ... and, beside it, how many sixths of a bit of each offset's count are group ceilings (the excess of the actual count over
+   the sum of nominal widths, 0 .. 414): what the engine's search turns into tighter monotone bounds */
+void orc_ac3enc_set_extra_curve(int *dst1024) { extra_curve = dst1024; }
 
 static int search_allocation(orc_ac3enc_t *s, int frame_bits)
 {
@@ -504,7 +512,10 @@ static int search_allocation(orc_ac3enc_t *s, int frame_bits)
 
     if (spare_curve) {
         int g;
-        for (g = 0; g < 1024; g++) spare_curve[g] = try_offsets(s, tmp, frame_bits, p.floor, g >> 4, g & 15);
+        for (g = 0; g < 1024; g++) {
+            spare_curve[g] = try_offsets(s, tmp, frame_bits, p.floor, g >> 4, g & 15);
+            if (extra_curve) extra_curve[g] = last_extra6;
+        }
     }
 
     /* search order and acceptance exactly as ac3enc.cpp:921-967 */

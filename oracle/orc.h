@@ -93,6 +93,7 @@ void orc_ac3enc_spec_tables(int16_t *window256, uint8_t *latab256, uint16_t *hth
 void orc_ac3enc_debug_counts(long *collisions, long *negshift);
 void orc_ac3enc_set_marker(int v);      /* test aid: default 128 (ac3enc.cpp:1375-1413) */
 void orc_ac3enc_set_spare_curve(int *dst1024);  /* measurement aid: spare bits at every offset, see ac3enc_oracle.c */
+void orc_ac3enc_set_extra_curve(int *dst1024);  /* ... and the group ceilings in each count, in sixths of a bit */
 void orc_ac3enc_mdct512(int32_t *out256, const int16_t *in512);
 int orc_ac3enc_encode_frames(int freq, int bitrate, int channels, const int16_t *pcm, int n,
                              const uint8_t *chmap, uint8_t *out_or_null);

@@ -14,7 +14,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import _harness as H
 
 NC = 3
-MARGIN = 72
+MARGIN = 72         # rounds 2-3: a fit / miss by this many bits decides every lower / higher offset
+
+
+class Curve(np.ndarray):
+    """a frame's spare bits at all 1024 offsets; .extra: the group ceilings in each count, in sixths of a bit (0 .. 414) -
+    what the round-4 kernel turns into tighter bounds: spare >= 69 - extra/6 decides every lower offset, spare < -extra/6
+    every higher one (encode.hip, enc_search_kernel)"""
+    extra = None
 
 
 def curves(n, seed=99, second_gen=False, with_source=False):
@@ -35,7 +42,10 @@ def curves(n, seed=99, second_gen=False, with_source=False):
     cm = (ctypes.c_uint8 * 8)(*H.CHMAP6)
     out = []
     buf = np.zeros(1024, np.int32)
+    xbuf = np.zeros(1024, np.int32)
+    O.orc_ac3enc_set_extra_curve.argtypes = [ctypes.c_void_p]
     O.orc_ac3enc_set_spare_curve(buf.ctypes.data)
+    O.orc_ac3enc_set_extra_curve(xbuf.ctypes.data)
     frame = np.zeros(1536, np.uint8)
     for i in range(n):
         src = np.ascontiguousarray(pcm[i].reshape(-1))
@@ -52,8 +62,11 @@ def curves(n, seed=99, second_gen=False, with_source=False):
                 s16[b] = ref16
             src = np.ascontiguousarray(s16.reshape(-1))
         assert O.orc_ac3enc_encode_frames(48000, 384000, 6, H.P(src, H.i16p), 1, cm, H.P(frame, H.u8p)) == 0
-        out.append((buf.copy(), g_src) if with_source else buf.copy())
+        cv = buf.copy().view(Curve)
+        cv.extra = xbuf.copy()
+        out.append((cv, g_src) if with_source else cv)
     O.orc_ac3enc_set_spare_curve(None)
+    O.orc_ac3enc_set_extra_curve(None)
     return out
 
 
@@ -105,8 +118,10 @@ class Search:       # SnrSearch of encode.hip
         return s
 
 
-def run(curve, start, policy, hint=None):
-    """returns (sweeps, (csnr, fsnr)); hint: the source frame's offsets (a transcode's first sweep costs there)"""
+def run(curve, start, policy, hint=None, tight=True):
+    """returns (sweeps, (csnr, fsnr)); hint: the source frame's offsets (a transcode's first sweep costs there); tight: the
+    round-4 bounds from each costed offset's own ceilings (needs curve.extra), else the fixed +-72 bits of rounds 2-3"""
+    extra = getattr(curve, "extra", None) if tight else None
     known = {}
     st = {"fit_hi": -1, "fail_lo": 1 << 20, "gl": None, "gh": None}
     ss = Search(start)
@@ -127,8 +142,13 @@ def run(curve, start, policy, hint=None):
         for g in gs:
             sp = int(curve[g])
             known[g] = sp >= 0
-            if sp >= MARGIN and g > st["fit_hi"]: st["fit_hi"] = g
-            if sp <= -MARGIN and g < st["fail_lo"]: st["fail_lo"] = g
+            if extra is None:
+                if sp >= MARGIN and g > st["fit_hi"]: st["fit_hi"] = g
+                if sp <= -MARGIN and g < st["fail_lo"]: st["fail_lo"] = g
+            else:
+                e6 = int(extra[g])
+                if 6 * sp >= 414 - e6 and g > st["fit_hi"]: st["fit_hi"] = g
+                if 6 * sp < -e6 and g < st["fail_lo"]: st["fail_lo"] = g
             if sp >= 0 and (st["gl"] is None or g > st["gl"][0]): st["gl"] = (g, sp)
             if sp < 0 and (st["gh"] is None or g < st["gh"][0]): st["gh"] = (g, sp)
 
@@ -208,7 +228,8 @@ if __name__ == "__main__":
                     sw, got = run(c, s0, policy)
                     assert got == reference(c, s0), (got, reference(c, s0))
                     tot += sw
-                print("%-24s %-7s %-5s sweeps per frame %.2f" % (name, policy, start, tot / len(cs)))
+                old = sum(run(c, 40 if start == "cold" else reference(c, 40)[0], policy, tight=False)[0] for c in cs)
+                print("%-24s %-7s %-5s sweeps per frame %.2f (with the fixed +-72-bit bounds: %.2f)" % (name, policy, start, tot / len(cs), old / len(cs)))
     pairs = curves(n, seed=7, second_gen=True, with_source=True)
     tot = 0
     for c, g_src in pairs:

@@ -43,3 +43,30 @@ def test_probing_needs_fewer_sweeps(curves):
     ladder = sum(sim.run(c, 40, "ladder")[0] for c in cs)
     probe = sum(sim.run(c, 40, "probe")[0] for c in cs)
     assert probe < ladder
+
+
+def test_bounds_from_a_costed_offsets_own_ceilings_are_exact(curves):
+    """enc_search_kernel (round 4): with E = the group ceilings inside a costed offset's count (sixths of a bit, from the
+    oracle: orc_ac3enc_set_extra_curve), spare >= 69 - E/6 proves every lower offset fits and spare < -E/6 proves every
+    higher one fails.  Checked against the whole curve of every frame, for every offset that could be costed."""
+    sim, cs = curves
+    for c in cs:
+        fits = np.asarray(c) >= 0
+        x = c.extra
+        assert x is not None and 0 <= x.min() and x.max() <= 414
+        for g in range(1024):
+            sp, e6 = int(c[g]), int(x[g])
+            if 6 * sp >= 414 - e6:
+                assert fits[:g + 1].all(), g
+            if 6 * sp < -e6:
+                assert not fits[g:].any(), g
+
+
+def test_tight_bounds_never_need_more_sweeps(curves):
+    sim, cs = curves
+    for c in cs:
+        for start in (40, 12):
+            a, ga = sim.run(c, start, "probe", tight=False)
+            b, gb = sim.run(c, start, "probe", tight=True)
+            assert ga == gb == sim.reference(c, start)
+            assert b <= a
