@@ -121,6 +121,9 @@ struct DecodeLaunch {
     uint8_t *ws_rows = nullptr;     // [S][F][6][7][512]
     float *ws_cplco = nullptr;      // [S][F][6][90]
     uint32_t *ws_fpos = nullptr;    // [S][F]
+    // split front end, one-frame streams, identity routing: mantissas + transform in one kernel (decode_mx.hip) - no
+    // coefficient planes in HBM (coef unused), the caller does not launch the transform
+    const XformLaunch *fuse = nullptr;
 };
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream);
 // decode_wg.hip: one workgroup per stream; X == nullptr: coefficient planes (+ taps) to HBM as launch_decode does;

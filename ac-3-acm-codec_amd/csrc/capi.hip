@@ -712,7 +712,7 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags)
 
 int ac3mi_set_decode_mode(ac3mi_ctx *ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 5 || mode == 2) return AC3MI_ERR_ARG;       // (2: the one-kernel front end per frame, retired in round 4)
+    if (!ctx || mode < 0 || mode > 6 || mode == 2) return AC3MI_ERR_ARG;       // (2: the one-kernel front end per frame, retired in round 4)
     ctx->decode_mode = mode;
     return AC3MI_OK;
 }
@@ -754,6 +754,14 @@ static bool use_frame_parallel(const ac3mi_ctx *ctx, int n_streams, int frames_p
 static bool use_split(const ac3mi_ctx *ctx)
 {
     return ctx->decode_mode == 0 || ctx->decode_mode >= 4;
+}
+
+// ... and its mantissa kernel with the transform fused in (decode_mx.hip: no coefficient planes in HBM)?  Needs one-frame
+// streams (a block's overlap tail goes to the next block inside the frame's workgroup) and every coded plane an output
+// plane.  auto and mode 6: yes where that holds; modes 4 / 5 keep the two kernels (the bit-identity reference, A/B runs).
+static bool use_mantx(const ac3mi_ctx *ctx, int frames_per_stream, bool identity)
+{
+    return (ctx->decode_mode == 0 || ctx->decode_mode == 6) && frames_per_stream == 1 && identity;
 }
 
 // the encoder's workspace for `rows` channel-blocks (6 x channels per frame):
@@ -834,12 +842,14 @@ size_t ac3mi_workspace_bytes(const ac3mi_ctx *ctx)
     return ctx->ws_coef_bytes + ctx->ws_blksw_bytes + ctx->ws_enc_bytes + ctx->ws_tc_bytes + ctx->ws_draws_bytes + ctx->ws_split_bytes;
 }
 
-size_t ac3mi_transcode_workspace_plan(size_t frames, int n_in, int nfchans, int n_out)
+size_t ac3mi_transcode_workspace_plan(size_t frames, int frames_per_stream, int n_in, int nfchans, int n_out)
 {
     // what ac3mi_transcode_batch holds for a call (or tile) of `frames` frames: coefficient planes + block-switch flags and
     // per-frame level flags (ensure_ws), the split front end's arrays (split_bytes), the s16 PCM between transform and
     // encoder, the encoder's arrays (enc_ws_layout) - the same expressions the call allocates with
-    return frames * 6 * (size_t)n_in * 256 * sizeof(float) + (frames * 6 * (size_t)nfchans + 4 + frames) + split_bytes(frames) +
+    // (one-frame streams without a downmix: no coefficient planes, use_mantx)
+    const size_t planes = (frames_per_stream == 1 && n_in == n_out) ? 0 : frames * 6 * (size_t)n_in * 256 * sizeof(float);
+    return planes + (frames * 6 * (size_t)nfchans + 4 + frames) + split_bytes(frames) +
            (frames * 1536 * (size_t)n_out * 2 + 512) + enc_ws_layout(frames * 6 * (size_t)n_out).need;
 }
 
@@ -996,9 +1006,10 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     // liba52's overlap bookkeeping around frames with surround level 0: the front end tells the transform which they are
     const bool mixstate = ctx->mix_pending && X.plan.surr_mask && !identity;
     uint8_t *zs = nullptr;
+    const bool mantx = !wgk && !taps && use_split(ctx) && use_mantx(ctx, frames_per_stream, identity);
     if (!fused) {
         const size_t zs_off = blksw ? 0 : nfr * 6 * X.plan.nfchans + 4;
-        int r = ensure_ws(ctx, coef ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0));
+        int r = ensure_ws(ctx, (coef || mantx) ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0));
         if (r != AC3MI_OK) return r;
         if (mixstate) zs = ctx->ws_blksw + zs_off;
         if (!coef) coef = ctx->ws_coef;
@@ -1084,7 +1095,7 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         D.lfeon = desc->lfeon ? 1 : 0;
         D.dynrng_on = desc->dynrng ? 1 : 0;
         D.level = desc->level;
-        D.coef = coef + f0 * 6 * X.plan.n_in * 256;
+        D.coef = mantx ? nullptr : coef + f0 * 6 * X.plan.n_in * 256;
         D.blksw = blksw + f0 * 6 * X.plan.nfchans;
         D.zs = zs ? zs + f0 : nullptr;
         D.status = d_status + f0;
@@ -1102,7 +1113,6 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
         }
-        HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
         hipStream_t xs = ctx->stream;
         X.coef = D.coef;
         X.blksw = D.blksw;
@@ -1120,7 +1130,9 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
         X.n_streams = ns;
         X.frames = frames_per_stream;
         X.bias = desc->bias;
-        HIPCHK(ctx, launch_xform(ctx->tab, X, xs));
+        if (mantx) D.fuse = &X;                             // the mantissa kernel transforms too (decode_mx.hip)
+        HIPCHK(ctx, launch_decode(ctx->tab, D, ctx->stream));
+        if (!mantx) HIPCHK(ctx, launch_xform(ctx->tab, X, xs));
     }
     return AC3MI_OK;
 }
@@ -1342,7 +1354,14 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     // workspaces: decoder planes, float PCM + s16 PCM, encoder arrays
     const bool mixstate = ctx->mix_pending && X.plan.surr_mask;       // as in decode_impl
     const size_t zs_off = nfr * 6 * X.plan.nfchans + 4;
-    { const int r = ensure_ws(ctx, nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0)); if (r != AC3MI_OK) return r; }
+    bool identity = X.plan.n_in == X.plan.n_out;
+    for (int o = 0; o < X.plan.n_out && identity; o++)
+        for (int c = 0; c < X.plan.n_in; c++)
+            if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
+    const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
+    const bool split = !fused && use_split(ctx);
+    const bool mantx = split && use_mantx(ctx, frames_per_stream, identity);             // decode_mx.hip: mantissas + transform
+    { const int r = ensure_ws(ctx, mantx ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0)); if (r != AC3MI_OK) return r; }
     uint8_t *const zs = mixstate ? ctx->ws_blksw + zs_off : nullptr;
     const size_t s16_bytes = nfr * 1536 * n_out * 2;       // the transform writes s16 itself: no float PCM in between
     if (s16_bytes + 512 > ctx->ws_tc_bytes) {
@@ -1366,14 +1385,8 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         HIPCHK(ctx, hipMalloc(&ctx->ws_enc, need));
         ctx->ws_enc_bytes = need;
     }
-    bool identity = X.plan.n_in == X.plan.n_out;
-    for (int o = 0; o < X.plan.n_out && identity; o++)
-        for (int c = 0; c < X.plan.n_in; c++)
-            if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
-    const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
     const bool fp = !fused && use_frame_parallel(ctx, n_streams, frames_per_stream);
     if (fp) { const int r = ensure_draws(ctx, nfr); if (r != AC3MI_OK) return r; }
-    const bool split = !fused && use_split(ctx);
     if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Decoder front end, transform to s16, encoder: back to back on the context's stream.  (Until round 2 two chunks were
     // pipelined over two streams; profiles/transcode_overlap.py measured 12.20 ms with and 12.23 - 12.27 ms without it per
@@ -1394,7 +1407,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         D.lfeon = dd.lfeon ? 1 : 0;
         D.dynrng_on = dd.dynrng ? 1 : 0;
         D.level = dd.level;
-        D.coef = ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
+        D.coef = mantx ? nullptr : ctx->ws_coef + f0 * 6 * X.plan.n_in * 256;
         D.blksw = ctx->ws_blksw + f0 * 6 * X.plan.nfchans;
         D.zs = zs ? zs + f0 : nullptr;
         D.status = d_status + f0;
@@ -1410,7 +1423,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
             D.split = 1;
             D.ws_desc = w.desc; D.ws_fpos = w.fpos; D.ws_cplco = w.cplco; D.ws_rows = w.rows;
         }
-        if (fused) {
+        if (fused || mantx) {
             XformLaunch Y = X;
             Y.coef = nullptr;
             Y.blksw = nullptr;
@@ -1423,7 +1436,9 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
             Y.n_streams = ns;
             Y.frames = frames_per_stream;
             Y.bias = 384.0f;
-            return launch_decode_wg(ctx->tab, D, &Y, 0, ctx->stream);
+            if (fused) return launch_decode_wg(ctx->tab, D, &Y, 0, ctx->stream);
+            D.fuse = &Y;
+            return launch_decode(ctx->tab, D, ctx->stream);
         }
         return launch_decode(ctx->tab, D, ctx->stream);
     };
@@ -1480,7 +1495,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
         return launch_encode(ctx->tab, G, ctx->stream);
     };
     HIPCHK(ctx, front(0));
-    if (!fused) HIPCHK(ctx, middle(0, ctx->stream));
+    if (!fused && !mantx) HIPCHK(ctx, middle(0, ctx->stream));
     HIPCHK(ctx, back(0));
     return AC3MI_OK;
 }

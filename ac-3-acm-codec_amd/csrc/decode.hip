@@ -649,20 +649,6 @@ __global__ void lfsr_prefix_kernel(const uint32_t *draws, uint16_t *frame_lfsr, 
 // into LDS; wavefront b unpacks, dequantises and stores audio block b from its BlkDesc (mant_block, decode_common.h:
 // the code of the one-kernel front ends, rows and coupling coordinates from the workspace).  Nothing carries from one
 // block to the next, so the six run concurrently and a wavefront's dependent chain is a sixth of a frame.
-struct MantParams {
-    const uint8_t *frames;
-    const BlkDesc *desc;        // [S*F][6]
-    const uint8_t *rows;        // [S*F][6] row sets
-    const float *cplco;         // [S*F][6][5][18]
-    const uint32_t *frame_pos;  // [S*F]
-    float *coef;
-    const uint16_t *lfsr_seq;
-    const DecTables *tab;
-    unsigned n_frames;
-    int frame_stride, frame_bytes;
-    int acmod, lfeon, n_in, nfchans;
-};
-
 struct MantLDS {
     uint4 dsc[M2_NDESC];
     float qtab[760];
@@ -765,6 +751,8 @@ extern "C" __attribute__((visibility("default"))) int ac3mi_debug_dec_cycles(uns
 namespace ac3mi {
 #endif
 
+hipError_t launch_mantx(const DeviceTables &tab, const DecodeLaunch &L, const MantParams &M, hipStream_t stream);       // decode_mx.hip
+
 hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStream_t stream)
 {
     DecodeParams P;
@@ -833,6 +821,7 @@ hipError_t launch_decode(const DeviceTables &tab, const DecodeLaunch &L, hipStre
         M.n_in = P.n_in;
         M.nfchans = P.nfchans;
         static const int mant_pad = getenv("AC3MI_MANT_LDS_PAD") ? atoi(getenv("AC3MI_MANT_LDS_PAD")) : 0;      // profiling aid: occupancy proxy of a fused mantissa + transform workgroup
+        if (L.fuse) return launch_mantx(tab, L, M, stream);         // one-frame streams, no downmix: the transform in the same kernel
         hipLaunchKernelGGL(mant_kernel, dim3(units), dim3(384), (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + mant_pad, stream, M);
         return hipGetLastError();
     }

@@ -93,14 +93,6 @@ struct WgLDS {
     float dly[6][128];                      // overlap tails of the stream
 };
 
-// what the reference's converters make of a float sample at bias 384 (src/AC3ASM.asm:303-318: psubd, packssdw)
-__device__ __forceinline__ int16_t to_s16(float v)
-{
-    int i = (int)(__float_as_uint(v) - 0x43c00000u);
-    i = i > 32767 ? 32767 : i < -32768 ? -32768 : i;
-    return (int16_t)i;
-}
-
 // Measurement aid (make EXTRA=-DWG_STAMPS, a separate library): wave w of workgroup 0 records s_memtime at fixed points of
 // the first frame of its SECOND stream (warm caches) into a buffer nothing else reads; dumped by launch_decode_wg.
 #ifdef WG_STAMPS

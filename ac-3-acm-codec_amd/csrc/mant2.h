@@ -35,6 +35,21 @@ __host__ __device__ inline uint4 mant_desc2(uint32_t b)
     return make_uint4(inc, nbp | (obits << 8) | (per << 16) | (sh << 24), recip | (qbase << 16), ring | (zero << 16) | (coded << 24));
 }
 
+// arguments of the mantissa kernels (mant_kernel in decode.hip, mantx_kernel in decode_mx.hip)
+struct MantParams {
+    const uint8_t *frames;
+    const BlkDesc *desc;        // [S*F][6]
+    const uint8_t *rows;        // [S*F][6] row sets
+    const float *cplco;         // [S*F][6][5][18]
+    const uint32_t *frame_pos;  // [S*F]
+    float *coef;
+    const uint16_t *lfsr_seq;
+    const DecTables *tab;
+    unsigned n_frames;
+    int frame_stride, frame_bytes;
+    int acmod, lfeon, n_in, nfchans;
+};
+
 // wave-uniform state that runs on from segment to segment of a block
 struct Seg2 {
     uint32_t bit;           // first bit of the next segment
@@ -142,7 +157,8 @@ __device__ __forceinline__ float dither2(const int16_t *seq, uint32_t i) { retur
 // One audio block.  fetch(slot) -> the lane's row bytes and exponents of that slot's segment (uint2: row bytes, exponents):
 // one dword each (bins 4 lane .. 4 lane + 3), for the LFE (slot 5) one byte each (bin = lane, lanes 0..6).
 // seq1 = lfsr_seq + 1 + the generator's position before the block's first draw (draw k is seq1[k]).
-template <class Fetch, class Cplco>
+// PS: floats from one plane of cblk to the next (256 in HBM; mantx_kernel's planes in LDS are padded).
+template <int PS = 256, class Fetch, class Cplco>
 __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2 first, Cplco cplco_of, const uint8_t *cplbnd, const uint4 *dsc, uint8_t *ring,
                                             const uint32_t *frw, uint32_t frw_last, const float *qtab, const int16_t *seq1, bool lfsr_live,
                                             float *cblk, uint32_t bitpos, int lane)
@@ -219,10 +235,10 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
                 const int e = (int)((cur.y >> (8 * j)) & 0xffu);
                 out[j] = qv[j] * (sf_of(e) * g);              // (bins past the channel's end have no bits: 0)
             }
-            float *plane = cblk + (slot + B.in_lfe) * 256;
+            float *plane = cblk + (slot + B.in_lfe) * PS;
             if (slot == 1 && B.acmod == 2 && B.rematflg != 0 && !remat_late) {
                 // rematrix: parse.c:837-865.  Channel 0's bins were stored by this same lane.
-                float4 a4 = *reinterpret_cast<const float4 *>(plane - 256 + 4 * lane);
+                float4 a4 = *reinterpret_cast<const float4 *>(plane - PS + 4 * lane);
                 float a[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -234,7 +250,7 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
                         out[j] = x - v;
                     }
                 }
-                *reinterpret_cast<float4 *>(plane - 256 + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<float4 *>(plane - PS + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
             }
             if ((B.chincpl >> slot) & 1) {
                 // a coupled channel: its own bins, zeros up to the coupling range and from its end on (see mant_block)
@@ -269,7 +285,7 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
                         v = 0.f;
                         if ((B.dithmask >> c) & 1) { v = (sf_of(e) * co) * (lfsr_live ? dither2(seq1, cdc) : 0.f); cdc++; }
                     }
-                    if (in) cblk[(c + B.in_lfe) * 256 + bin] = v;
+                    if (in) cblk[(c + B.in_lfe) * PS + bin] = v;
                 }
                 cd += zero ? (uint32_t)draws : 0u;
             }
@@ -279,7 +295,7 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        volatile float *p0 = cblk + (size_t)B.in_lfe * 256, *p1 = p0 + 256;
+        volatile float *p0 = cblk + (size_t)B.in_lfe * PS, *p1 = p0 + PS;
         for (int bin = 13 + lane; bin < remat_end; bin += 64) {
             const int band = bin < 25 ? 0 : bin < 37 ? 1 : bin < 61 ? 2 : 3;
             if ((B.rematflg >> band) & 1) {

@@ -56,14 +56,6 @@ struct XformParams {
     int downmixing;             // fewer full-bandwidth outputs than coded channels (parse.c:881-883)
 };
 
-// what the reference's converters make of a float sample at bias 384 (src/AC3ASM.asm:303-318: psubd, packssdw)
-__device__ __forceinline__ int16_t to_s16(float v)
-{
-    int i = (int)(__float_as_uint(v) - 0x43c00000u);
-    i = i > 32767 ? 32767 : i < -32768 ? -32768 : i;
-    return (int16_t)i;
-}
-
 // long-block input pattern: lane l8 owns m = 8*n1 + l8
 __device__ __forceinline__ void load_long(const float *plane, int l8, float sign, float (&xa)[16], float (&xb)[16])
 {

@@ -208,6 +208,14 @@ __device__ __forceinline__ void window_pair(float f0, float f1, float2 d, float2
     hi.y = __builtin_fmaf(-f0, whi.y, __builtin_fmaf(d.x, wlo.x, bias));       // out[255-2i]
 }
 
+// what the reference's converters make of a float sample at bias 384 (src/AC3ASM.asm:303-318: psubd, packssdw)
+__device__ __forceinline__ int16_t to_s16(float v)
+{
+    int i = (int)(__float_as_uint(v) - 0x43c00000u);
+    i = i > 32767 ? 32767 : i < -32768 ? -32768 : i;
+    return (int16_t)i;
+}
+
 __device__ __forceinline__ void imdct_long_second_half(cf (&r)[16], FirstTail &ft);
 __device__ __forceinline__ void imdct_short_second_half(cf (&r)[16], FirstTail &ft);
 

@@ -252,7 +252,8 @@ class Engine:
 
     def set_decode_mode(self, mode):
         """0 = choose by batch shape, 1 = one wavefront per stream (one-kernel reference), 3 = one workgroup per stream with the
-        transform fused in, 4 / 5 = parse kernel per stream / per frame + one wavefront per audio block (ac3mi_set_decode_mode)."""
+        transform fused in, 4 / 5 = parse kernel per stream / per frame + one wavefront per audio block, 6 = as 4 with the transform
+        in the mantissa kernel for one-frame streams without a downmix (ac3mi_set_decode_mode)."""
         self._check(self.lib.ac3mi_set_decode_mode(ctypes.c_void_p(self.ctx), int(mode)))
 
     def set_encode_mode(self, mode):

@@ -49,13 +49,13 @@ def plan_transcode_bytes(streams, frames_per_stream=1, tile_frames=131072, frame
     from .capi import load_library
     lib = load_library()
     lib.ac3mi_transcode_workspace_plan.restype = ctypes.c_size_t
-    lib.ac3mi_transcode_workspace_plan.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.ac3mi_transcode_workspace_plan.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     nfr = streams * frames_per_stream
     per_stream = 2 * frames_per_stream * frame_bytes + frames_per_stream * 4      # frames in + out, status
     per_stream += 6 * 128 * 4 + 2 + nch * 256 * 2 + 4                              # overlap tails, dither state, encoder history, search state
     tile = min(nfr, max(tile_frames, frames_per_stream)) if tile_frames else nfr
     nfchans = nch - 1 if nch == 6 else nch                                         # (5.1: five full-bandwidth channels + LFE)
-    workspace = int(lib.ac3mi_transcode_workspace_plan(tile, nch, nfchans, nch))
+    workspace = int(lib.ac3mi_transcode_workspace_plan(tile, frames_per_stream, nch, nfchans, nch))
     total = streams * per_stream + workspace
     return {"streams": streams, "state_and_io": streams * per_stream, "workspace": workspace, "tile_frames": tile,
             "total": total, "fits": total < HBM_BYTES}

@@ -118,7 +118,25 @@ class Search:       # SnrSearch of encode.hip
         return s
 
 
-def run(curve, start, policy, hint=None, tight=True):
+def quad_root(pts, gl, gh, ge):
+    """zero of the parabola through the last sweep's three costed points, inside (gl, gh); the line's estimate otherwise"""
+    (x0, y0), (x1, y1), (x2, y2) = sorted(pts)
+    if x0 == x1 or x1 == x2: return ge
+    d1 = (y1 - y0) / (x1 - x0); d2 = (y2 - y1) / (x2 - x1)
+    a = (d2 - d1) / (x2 - x0)
+    b = d1 - a * (x0 + x1)
+    c = y0 - x0 * (a * x0 + b)
+    if abs(a) < 1e-9: return ge
+    disc = b * b - 4 * a * c
+    if disc < 0: return ge
+    r = disc ** 0.5
+    best = None
+    for z in ((-b - r) / (2 * a), (-b + r) / (2 * a)):
+        if gl <= z <= gh and (best is None or abs(z - ge) < abs(best - ge)): best = z
+    return ge if best is None else best
+
+
+def run(curve, start, policy, hint=None, tight=True, quad=False, qd=(2, 1), rnd=0.5):
     """returns (sweeps, (csnr, fsnr)); hint: the source frame's offsets (a transcode's first sweep costs there); tight: the
     round-4 bounds from each costed offset's own ceilings (needs curve.extra), else the fixed +-72 bits of rounds 2-3"""
     extra = getattr(curve, "extra", None) if tight else None
@@ -130,6 +148,7 @@ def run(curve, start, policy, hint=None, tight=True):
     first = True
     cold = start == 40
     probes_done = 0
+    last = []
 
     def lookup(g):
         if g <= st["fit_hi"]: return True
@@ -139,9 +158,11 @@ def run(curve, start, policy, hint=None, tight=True):
     def cost(gs):
         nonlocal sweeps
         sweeps += 1
+        last.clear()
         for g in gs:
             sp = int(curve[g])
             known[g] = sp >= 0
+            last.append((g, sp))
             if extra is None:
                 if sp >= MARGIN and g > st["fit_hi"]: st["fit_hi"] = g
                 if sp <= -MARGIN and g < st["fail_lo"]: st["fail_lo"] = g
@@ -170,6 +191,10 @@ def run(curve, start, policy, hint=None, tight=True):
                 w = gh - gl
                 ge = gl + int(w * (sl / (sl - sh)) + 0.5)
                 d = max(2, (w * 85) >> 10) if w > 48 else 1
+                if quad and len(last) == 3:
+                    z = quad_root(last, gl, gh, gl + w * (sl / (sl - sh)))
+                    ge = int(z + rnd)
+                    d = qd[0] if w > 48 else qd[1]
                 for g in (ge, ge + d, ge - d):
                     g = min(max(g, gl + 1), gh - 1)
                     if g not in cand: cand.append(g)

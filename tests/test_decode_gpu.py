@@ -266,6 +266,75 @@ def test_frame_parallel_front_end_equals_the_serial_one(engine, source):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), other
 
 
+@pytest.mark.parametrize("acmod,lfe,source", [(7, 1, "encoder"), (7, 1, "packer"), (2, 0, "packer"), (3, 1, "packer"), (1, 0, "packer"), (6, 0, "packer")])
+def test_fused_mantissa_transform_kernel_equals_the_two_kernels(engine, acmod, lfe, source):
+    """ac3mi_set_decode_mode 6 (what auto picks for one-frame streams without a downmix): mantx_kernel (decode_mx.hip) unpacks
+    a block's mantissas into LDS planes and transforms them in the same wavefront, overlap tails from block to block through
+    LDS - against mode 4 (mant_kernel, planes through HBM, xform_kernel).  Same PCM (float and s16), status, overlap state and
+    dither state, bit for bit: encoder output (dither-heavy quiet frames), packer streams with coupling, rematrixing, block
+    switching and delta bit allocation, non-zero overlap state coming in, damaged frames (failed blocks leave zero planes),
+    and state slots."""
+    import torch
+    from tests import packer
+    pkg = H.pkg()
+    if source == "encoder":
+        F = 4
+        streams = [H.orc_encode(H.gen_pcm(F, 6, seed=700 + s, kind=("quiet", "tones", "bursts", "music", "noise")[s % 5])) for s in range(10)]
+    else:
+        F = 5
+        streams = [packer.make_stream(5100 + 7 * s + acmod, F, acmod, lfe) for s in range(10)]
+    frames = np.stack(streams)
+    fb = frames.shape[2]
+    stride = (fb + 3) & ~3
+    S = frames.shape[0] * F                                 # every frame a one-frame stream of its own
+    padded = np.zeros((S, 1, stride), np.uint8)
+    padded[:, 0, :fb] = frames.reshape(S, fb)
+    rng = np.random.default_rng(acmod * 10 + lfe)
+    for s in (3, 11):                                       # damage: a header that fails, and bits flipped mid-frame
+        padded[s, 0, 0] ^= 0xff
+    padded[7, 0, fb // 2:fb // 2 + 8] ^= rng.integers(1, 255, 8).astype(np.uint8)
+    d_frames = torch.from_numpy(padded).cuda()
+    flags = acmod | (16 if lfe else 0)
+    res = {}
+    try:
+        for mode in (4, 6):
+            engine.set_decode_mode(mode)
+            out = []
+            for bias, s16, slots in ((0.0, False, False), (384.0, True, False), (384.0, True, True)):
+                desc = pkg.DecodeDesc(flags=flags | 32, level=1.0, bias=bias, dynrng=1, acmod=acmod, lfeon=lfe, frame_bytes=fb)
+                n_out, _ = engine.decode_planes(desc)
+                if slots and n_out != 6:                    # (slot strides are those of six planes)
+                    continue
+                g = torch.Generator().manual_seed(5)
+                delay = ((torch.rand((S, n_out, 128), generator=g) - 0.5) * 0.25).cuda()
+                lfsr = torch.ones((S,), dtype=torch.int16, device="cuda")
+                lfsr[5] = 0x1234
+                lfsr[6] = 0
+                if slots:                                   # stream s keeps its state in slot perm[s]
+                    perm = torch.randperm(S, generator=g).to(torch.int32).cuda()
+                    engine._check(engine.lib.ac3mi_set_state_slots(ctypes.c_void_p(engine.ctx), ctypes.c_void_p(perm.data_ptr())))
+                try:
+                    if s16:
+                        pcm, status = engine.decode_s16_batch(desc, d_frames, delay, lfsr)
+                    else:
+                        pcm, status = engine.decode_batch(desc, d_frames, delay, lfsr)
+                    engine.sync()
+                finally:
+                    if slots:
+                        engine._check(engine.lib.ac3mi_set_state_slots(ctypes.c_void_p(engine.ctx), None))
+                out += [x.cpu().numpy() for x in (pcm, status, delay, lfsr)]
+            res[mode] = out
+    finally:
+        import os
+        engine.set_decode_mode(int(os.environ.get("AC3MI_DECODE_MODE", "0")))
+    st = res[4][1].reshape(-1)
+    assert (st[[3, 11]] & 0x100).all() and (np.delete(st, [3, 7, 11]) & 0x1ff).max() == 0
+    assert np.abs(res[4][0]).max() > 1e-3
+    for k, (a, b) in enumerate(zip(res[4], res[6])):
+        diff = np.argwhere(a.view(np.uint8).reshape(a.shape[0], -1) != b.view(np.uint8).reshape(b.shape[0], -1))
+        assert diff.size == 0, (k, a.shape, sorted(set(diff[:, 0].tolist())), diff[:8].tolist())
+
+
 @pytest.mark.parametrize("acmod,lfe,req", [(7, 1, 7 | 16), (7, 1, 2), (2, 0, 2), (7, 1, 10), (3, 1, 3 | 16), (1, 0, 1), (6, 0, 6), (7, 0, 4)])
 def test_decode_s16_equals_decode_plus_converter(engine, acmod, lfe, req):
     """ac3mi_decode_s16_batch (the transform writes interleaved s16 itself) against ac3mi_decode_batch at level 1 / bias
