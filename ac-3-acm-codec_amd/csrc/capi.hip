@@ -758,10 +758,13 @@ static bool use_split(const ac3mi_ctx *ctx)
 
 // ... and its mantissa kernel with the transform fused in (decode_mx.hip: no coefficient planes in HBM)?  Needs one-frame
 // streams (a block's overlap tail goes to the next block inside the frame's workgroup) and every coded plane an output
-// plane.  auto and mode 6: yes where that holds; modes 4 / 5 keep the two kernels (the bit-identity reference, A/B runs).
-static bool use_mantx(const ac3mi_ctx *ctx, int frames_per_stream, bool identity)
+// plane.  Mode 6: wherever that holds; auto: for s16 output only - measured per 65 536 5.1 frames (profiles/r04_kernel_stats.csv,
+// profiles/EXPERIMENTS.md): to s16 2.12 - 2.17 ms fused against 1.31 + 0.77 = 2.08 - 2.15 ms in two kernels (a wash in time,
+// 36.9 KB per frame less HBM traffic and workspace), to float 2.45 against 1.31 + 0.97 = 2.28 ms (the two kernels stay);
+// modes 4 / 5 always keep the two kernels (the bit-identity reference, A/B runs).
+static bool use_mantx(const ac3mi_ctx *ctx, int frames_per_stream, bool identity, bool s16)
 {
-    return (ctx->decode_mode == 0 || ctx->decode_mode == 6) && frames_per_stream == 1 && identity;
+    return ((ctx->decode_mode == 0 && s16) || ctx->decode_mode == 6) && frames_per_stream == 1 && identity;
 }
 
 // the encoder's workspace for `rows` channel-blocks (6 x channels per frame):
@@ -1006,7 +1009,7 @@ static int decode_impl(ac3mi_ctx *ctx, const ac3mi_decode_desc *desc, const uint
     // liba52's overlap bookkeeping around frames with surround level 0: the front end tells the transform which they are
     const bool mixstate = ctx->mix_pending && X.plan.surr_mask && !identity;
     uint8_t *zs = nullptr;
-    const bool mantx = !wgk && !taps && use_split(ctx) && use_mantx(ctx, frames_per_stream, identity);
+    const bool mantx = !wgk && !taps && use_split(ctx) && use_mantx(ctx, frames_per_stream, identity, d_pcm16 != nullptr);
     if (!fused) {
         const size_t zs_off = blksw ? 0 : nfr * 6 * X.plan.nfchans + 4;
         int r = ensure_ws(ctx, (coef || mantx) ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0));
@@ -1360,7 +1363,7 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
             if (X.plan.mix[o][c] != (o == c ? 1 : 0)) identity = false;
     const bool fused = identity && use_wg_kernel(ctx, n_streams, frames_per_stream);     // decode_wg.hip writes the s16 PCM itself
     const bool split = !fused && use_split(ctx);
-    const bool mantx = split && use_mantx(ctx, frames_per_stream, identity);             // decode_mx.hip: mantissas + transform
+    const bool mantx = split && use_mantx(ctx, frames_per_stream, identity, true);             // decode_mx.hip: mantissas + transform
     { const int r = ensure_ws(ctx, mantx ? 0 : nfr * 6 * X.plan.n_in * 256 * sizeof(float), zs_off + (mixstate ? nfr : 0)); if (r != AC3MI_OK) return r; }
     uint8_t *const zs = mixstate ? ctx->ws_blksw + zs_off : nullptr;
     const size_t s16_bytes = nfr * 1536 * n_out * 2;       // the transform writes s16 itself: no float PCM in between

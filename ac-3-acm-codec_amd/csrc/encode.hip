@@ -1079,9 +1079,10 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
             bool probing = false;
             if (probe_sweeps < 3 && gl >= 0 && gh > gl + 3) {
                 const int w = gh - gl;
-                const int ge = gl + (int)((float)w * ((float)spare_l / (float)(spare_l - spare_h)) + 0.5f);
+                const float est = (float)w * ((float)spare_l / (float)(spare_l - spare_h));       // relative to gl
                 int d = w > 48 ? (w * 85) >> 10 : 1;
                 d = d < 2 && w > 48 ? 2 : d;
+                const int ge = gl + (int)(est + 0.5f);
                 auto clampg = [&](int g) { return g < gl + 1 ? gl + 1 : g > gh - 1 ? gh - 1 : g; };
                 add(clampg(ge));
                 add(clampg(ge + d));

@@ -390,6 +390,15 @@ def secondary_timings(pkg, eng, dev, C, rank, dist, barrier, steps=20, checks=Tr
                 wms = timed(fn, None)
                 res[name]["warm"] = {"frames_per_s_per_gpu": S / (wms * 1e-3), "ms_per_pass": wms,
                                      "state": "warm: every pass continues the streams of the pass before (same content: the search starts at its optimum)"}
+    # the same decode with the mantissa kernel and the transform as two kernels (ac3mi_set_decode_mode 4; auto fuses them for
+    # one-frame streams, decode_mx.hip): the standing A/B of the fusion, and what keeps both kernels in the profiles
+    eng.set_decode_mode(4)
+    try:
+        ms2 = timed(do_dec16, None)
+    finally:
+        eng.set_decode_mode(int(os.environ.get("AC3MI_DECODE_MODE", "0")))
+    res["decode_s16"]["two_kernels"] = {"ms_per_pass": ms2, "frames_per_s_per_gpu": S / (ms2 * 1e-3),
+                                        "what": "ac3mi_set_decode_mode 4: coefficient planes through HBM between mant_kernel and xform_kernel (36.9 KB written and read per frame)"}
     if warm:
         wms = timed(C.transcode, None)
         res["transcode_warm"] = {"frames_per_s_per_gpu": S / (wms * 1e-3), "ms_per_pass": wms,

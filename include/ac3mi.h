@@ -151,8 +151,9 @@ int ac3mi_set_mix_state(ac3mi_ctx *ctx, float *d_pending, int32_t *d_flags);
  *   6  as 4, and for one-frame streams whose coded planes are the output planes (no downmix) the second kernel also
  *      transforms: the six wavefronts of a frame hand each other their overlap tails through LDS, the coefficient planes
  *      never reach HBM and the transform kernel is not launched (other calls: as 4);
- *   0  (default) choose by batch shape: 3 for up to 512 streams of at most four frames, else 6, or 5 for fewer than 5 120
- *      streams of more than one frame.
+ *   0  (default) choose by batch shape: 3 for up to 512 streams of at most four frames, else 4 - with 6's fused kernel where
+ *      the output is s16 (ac3mi_decode_s16_batch, ac3mi_transcode_batch; to float the two kernels are faster) - or 5 for
+ *      fewer than 5 120 streams of more than one frame.
  * (2, a one-kernel front end per frame, was retired in round 4: AC3MI_ERR_ARG.)
  * Conforming streams decode to the same bits in every variant: block 0 of a frame re-sends exponents, coupling and
  * bit-allocation parameters, so only the dither generator's state and the overlap tails carry from frame to frame, and

@@ -76,6 +76,8 @@ ALG = {
     "decode_kernel<0>": 1536 + 36864,
     "decode_kernel<4>": 1536 + 480,             # frame in, six block descriptors out (+ the rows that changed: data-dependent)
     "mant_kernel": 1536 + 480 + 36864,          # frame + descriptors in (+ the rows of every segment), planes out
+    "mantx_kernel<true>": 1536 + 480 + 18432 + 6144,    # ... s16 PCM out instead, overlap state in and out
+    "mantx_kernel<false>": 1536 + 480 + 36864 + 6144,   # ... float PCM out
     "decode_wg_kernel<0>": 1536 + 36864,
     "decode_wg_kernel<1>": 1536 + 36864 + 6144,
     "decode_wg_kernel<2>": 1536 + 18432 + 6144,
@@ -122,13 +124,19 @@ for k, d in mixa.items():
 
 
 def pick(*prefixes):
-    return [k for k in kern if any(k.startswith(p) for p in prefixes)]
+    # (only kernels whose largest launch covered the whole batch - at least a wavefront per frame: the small-batch kernels of
+    # the per-stream curve would otherwise enter a leg with counts divided by the wrong number of frames; the transform kernels run
+    # eight chains per wavefront)
+    return [k for k in kern if any(k.startswith(p) for p in prefixes) and (kern[k].get("waves") or 0) >= frames // 8]
 
 
+# what one pass of a bench leg launches (round 4: to s16 the mantissa kernel transforms too, decode_mx.hip; the s16 transform
+# kernel runs in the `two_kernels` A/B of the decode_s16 leg only)
 legs = {
-    "decode": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<1>", "decode_wg_kernel<0>", "xform_kernel<false, 4, false>"),
-    "decode_s16": pick("decode_kernel<0>", "decode_kernel<4>", "mant_kernel", "decode_wg_kernel<2>", "xform_kernel<false, 3, true>"),
-    "encode": pick("enc_mdct_kernel", "enc_pack_kernel<0>", "enc_pack_kernel<1>", "enc_pack_kernel<2>", "enc_search_kernel<1>", "enc_packf_kernel", "enc_packb_kernel"),
+    "decode": pick("decode_kernel<4>", "mant_kernel", "xform_kernel<false, 4, false>"),
+    "decode_s16": pick("decode_kernel<4>", "mantx_kernel<true>"),
+    "decode_s16_two_kernels": pick("decode_kernel<4>", "mant_kernel", "xform_kernel<false, 3, true>"),
+    "encode": pick("enc_mdct_kernel", "enc_search_kernel<1>", "enc_packf_kernel"),
     "transform_downmix_mixed_blocks": pick("xform_kernel<true, 2, false>", "xform_kernel<true, 3, false>"),
 }
 legs["transcode"] = sorted(set(legs["decode_s16"]) | set(legs["encode"]))
