@@ -174,10 +174,10 @@ int ac3mi_set_encode_mode(ac3mi_ctx *ctx, int mode);
 
 /* Workspace bound (new; results do not depend on it, except for frames flagged AC3MI_STATUS_REUSE0 at a tile boundary).  ac3mi_decode_batch, ac3mi_encode_batch and ac3mi_transcode_batch keep
  * their intermediates (coefficient planes, MDCT coefficients, exponents, PCM between decoder and encoder: 37 / 60 /
- * 152 KB per frame) in workspaces owned by the context.  A batch of more than `frames` frames goes through in tiles
+ * 102 - 139 KB per 5.1 frame) in workspaces owned by the context.  A batch of more than `frames` frames goes through in tiles
  * of whole streams of at most that many frames each (at least one stream), one after the other on the context's
  * streams, so the workspaces stop growing with the batch: a million-stream call needs its own input, output and state
- * arrays plus a fixed ~20 GB.  Default 131072; 0 = never tile.  Calls that ask for stage taps are not tiled. */
+ * arrays plus a fixed 13 - 18 GB.  Default 131072; 0 = never tile.  Calls that ask for stage taps are not tiled. */
 int ac3mi_set_tile_frames(ac3mi_ctx *ctx, long long frames);
 
 /* Workspace accounting (new).  ac3mi_workspace_bytes: device bytes the context's workspaces hold right now (they only grow,
