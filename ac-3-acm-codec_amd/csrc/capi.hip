@@ -472,7 +472,7 @@ ac3mi_ctx *ac3mi_create(int device)
     ctx->decode_mode = 0;
     if (const char *e = getenv("AC3MI_DECODE_MODE")) {          // test aid: default front-end variant (ac3mi_set_decode_mode)
         const int m = atoi(e);
-        if (m >= 0 && m <= 5 && m != 2) ctx->decode_mode = m;
+        if (m >= 0 && m <= 6 && m != 2) ctx->decode_mode = m;
     }
     ctx->tile_frames = 131072;
     ctx->encode_mode = 0;

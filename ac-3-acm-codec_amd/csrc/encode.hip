@@ -124,65 +124,78 @@ __device__ __forceinline__ uint32_t bytes_min_where(uint32_t a, uint32_t b, uint
 // two for D25, one for D45 (entry i covers bins 1 + (i-1) gs .. + gs-1, so groups never straddle lanes).  The +-2 delta
 // constraint, min over j of g[j] + 2|i-j|, is a prefix minimum of g[j] - 2j followed by a suffix minimum of g[j] + 2j: inside
 // the lane first, then ONE scan over the lane totals per direction.
-__device__ int encode_exp_wave(uint8_t *row, int n, int strategy, int lane)
+// PER = entries per lane, a compile-time constant per strategy (D15 4, D25 2, D45 1): a reuse-poor frame (decoded audio
+// re-encoded sends 24 sets, most of them D45 / D25) spends its exponent stage here, and the coarse strategies need a quarter /
+// half of the per-entry work.
+template <int PER>
+__device__ __forceinline__ int encode_exp_wave_t(uint8_t *row, int n, int lane)
 {
     constexpr int INF = 0x3fffffff;
-    const int gs = strategy == 1 ? 1 : strategy == 2 ? 2 : 4;
-    const int per = strategy == 1 ? 4 : strategy == 2 ? 2 : 1;             // entries per lane
+    constexpr int gs = PER == 4 ? 1 : PER == 2 ? 2 : 4;
     const int ng = ((n + gs * 3 - 4) / (3 * gs)) * 3;
     uint32_t *q = reinterpret_cast<uint32_t *>(row);
     const uint32_t own = q[lane], nxt = q[lane + 1];        // lane 63 reads the dword behind the row: entries beyond ng, never used
     const uint32_t S = __builtin_amdgcn_alignbyte(nxt, own, 1u);
     const int b0 = (int)(S & 0xffu), b1 = (int)((S >> 8) & 0xffu), b2 = (int)((S >> 16) & 0xffu), b3 = (int)(S >> 24);
-    const int m01 = b1 < b0 ? b1 : b0, m23 = b3 < b2 ? b3 : b2, m03 = m23 < m01 ? m23 : m01;
     int row0 = (int)(__builtin_amdgcn_readfirstlane((int)own) & 0xff);
     row0 = row0 > 15 ? 15 : row0;
-    int g[4], ix[4];
-    bool valid[4];
-    g[0] = per == 4 ? b0 : per == 2 ? m01 : m03;
-    g[1] = per == 4 ? b1 : m23;
-    g[2] = b2;
-    g[3] = b3;
+    int g[PER], ix[PER];
+    bool valid[PER];
+    if (PER == 4) { g[0] = b0; g[PER > 1 ? 1 : 0] = b1; g[PER > 2 ? 2 : 0] = b2; g[PER > 3 ? 3 : 0] = b3; }
+    else if (PER == 2) { g[0] = b1 < b0 ? b1 : b0; g[PER > 1 ? 1 : 0] = b3 < b2 ? b3 : b2; }
+    else { const int m01 = b1 < b0 ? b1 : b0, m23 = b3 < b2 ? b3 : b2; g[0] = m23 < m01 ? m23 : m01; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        ix[c] = 2 * (per * lane + 1 + c);
-        valid[c] = c < per && per * lane + 1 + c <= ng;
+    for (int c = 0; c < PER; c++) {
+        ix[c] = 2 * (PER * lane + 1 + c);
+        valid[c] = PER * lane + 1 + c <= ng;
     }
-    int t[4];
+    int t[PER];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < PER; c++) {
         const int a = valid[c] ? g[c] - ix[c] : INF;
-        t[c] = c == 0 ? a : (a < t[c - 1] ? a : t[c - 1]);
+        t[c] = c == 0 ? a : (a < t[c > 0 ? c - 1 : 0] ? a : t[c > 0 ? c - 1 : 0]);
     }
     {
-        int ex = __builtin_amdgcn_update_dpp(INF, wave_incl_scan_min(t[3]), 0x138, 0xf, 0xf, false);       // wave_shr:1
+        int ex = __builtin_amdgcn_update_dpp(INF, wave_incl_scan_min(t[PER - 1]), 0x138, 0xf, 0xf, false);       // wave_shr:1
         ex = row0 < ex ? row0 : ex;
 #pragma unroll
-        for (int c = 0; c < 4; c++) g[c] = (t[c] < ex ? t[c] : ex) + ix[c];
+        for (int c = 0; c < PER; c++) g[c] = (t[c] < ex ? t[c] : ex) + ix[c];
     }
 #pragma unroll
-    for (int c = 3; c >= 0; c--) {
+    for (int c = PER - 1; c >= 0; c--) {
         const int a = valid[c] ? g[c] + ix[c] : INF;
-        t[c] = c == 3 ? a : (a < t[c + 1] ? a : t[c + 1]);
+        t[c] = c == PER - 1 ? a : (a < t[c < PER - 1 ? c + 1 : c] ? a : t[c < PER - 1 ? c + 1 : c]);
     }
     const int suf = wave_suffix_scan_min(t[0], lane);
     {
         const int ex = __builtin_amdgcn_update_dpp(INF, suf, 0x130, 0xf, 0xf, false);                       // wave_shl:1
 #pragma unroll
-        for (int c = 0; c < 4; c++) g[c] = (t[c] < ex ? t[c] : ex) - ix[c];
+        for (int c = 0; c < PER; c++) g[c] = (t[c] < ex ? t[c] : ex) - ix[c];
     }
     const int head = __builtin_amdgcn_readfirstlane(suf);
     const int row0new = head < row0 ? head : row0;
     // back to bins (entries beyond ng leave their bins alone)
-    const int e1 = per == 4 ? 1 : 0, e2 = per == 4 ? 2 : per == 2 ? 1 : 0, e3 = per == 4 ? 3 : per == 2 ? 1 : 0;
-    const int g1 = e1 ? g[1] : g[0], g2 = e2 == 2 ? g[2] : e2 == 1 ? g[1] : g[0], g3 = e3 == 3 ? g[3] : e3 == 1 ? g[1] : g[0];
-    const bool v1 = e1 ? valid[1] : valid[0], v2 = e2 == 2 ? valid[2] : e2 == 1 ? valid[1] : valid[0];
-    const bool v3 = e3 == 3 ? valid[3] : e3 == 1 ? valid[1] : valid[0];
-    const uint32_t o = (uint32_t)(valid[0] ? g[0] : b0) | (uint32_t)(v1 ? g1 : b1) << 8 | (uint32_t)(v2 ? g2 : b2) << 16 |
-                       (uint32_t)(v3 ? g3 : b3) << 24;
+    int o0, o1, o2, o3;
+    if (PER == 4) {
+        o0 = valid[0] ? g[0] : b0; o1 = valid[PER > 1 ? 1 : 0] ? g[PER > 1 ? 1 : 0] : b1;
+        o2 = valid[PER > 2 ? 2 : 0] ? g[PER > 2 ? 2 : 0] : b2; o3 = valid[PER > 3 ? 3 : 0] ? g[PER > 3 ? 3 : 0] : b3;
+    } else if (PER == 2) {
+        o0 = valid[0] ? g[0] : b0; o1 = valid[0] ? g[0] : b1;
+        o2 = valid[PER > 1 ? 1 : 0] ? g[PER > 1 ? 1 : 0] : b2; o3 = valid[PER > 1 ? 1 : 0] ? g[PER > 1 ? 1 : 0] : b3;
+    } else {
+        o0 = valid[0] ? g[0] : b0; o1 = valid[0] ? g[0] : b1; o2 = valid[0] ? g[0] : b2; o3 = valid[0] ? g[0] : b3;
+    }
+    const uint32_t o = (uint32_t)o0 | (uint32_t)o1 << 8 | (uint32_t)o2 << 16 | (uint32_t)o3 << 24;
     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(row0new << 24, (int)o, 0x138, 0xf, 0xf, false);
     q[lane] = __builtin_amdgcn_alignbyte(o, prev, 3u);
     return 4 + (ng / 3) * 7;
+}
+
+__device__ int encode_exp_wave(uint8_t *row, int n, int strategy, int lane)
+{
+    if (strategy == 1) return encode_exp_wave_t<4>(row, n, lane);
+    if (strategy == 2) return encode_exp_wave_t<2>(row, n, lane);
+    return encode_exp_wave_t<1>(row, n, lane);
 }
 
 // Masking curve of one row, one lane per band (:220-367).  bndpsd[] must hold the band PSDs.
@@ -1087,6 +1100,13 @@ __global__ __launch_bounds__(64, ENC_SEARCH_LB) void enc_search_kernel(const Pac
                 add(clampg(ge));
                 add(clampg(ge + d));
                 add(clampg(ge - d));
+                // candidates that clamped onto each other (an estimate at the bracket's edge): the nearest uncosted neighbours
+                // take their places - a sweep costs the same with one offset or three (2.35 -> 2.29 sweeps per transcoded frame,
+                // 3.23 -> 3.16 per fresh one, and the tails shorter: profiles/search_sim.py)
+                for (int k = 1; n_cand < ENC_NC && k < w; k++) {
+                    if (ge - k > gl && ge - k < gh) add(ge - k);
+                    if (n_cand < ENC_NC && ge + k > gl && ge + k < gh) add(ge + k);
+                }
                 probe_sweeps++;
                 probing = true;
             }

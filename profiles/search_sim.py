@@ -136,9 +136,11 @@ def quad_root(pts, gl, gh, ge):
     return ge if best is None else best
 
 
-def run(curve, start, policy, hint=None, tight=True, quad=False, qd=(2, 1), rnd=0.5):
+def run(curve, start, policy, hint=None, tight=True, quad=False, qd=(2, 1), rnd=0.5, fill=True):
     """returns (sweeps, (csnr, fsnr)); hint: the source frame's offsets (a transcode's first sweep costs there); tight: the
-    round-4 bounds from each costed offset's own ceilings (needs curve.extra), else the fixed +-72 bits of rounds 2-3"""
+    round-4 bounds from each costed offset's own ceilings (needs curve.extra), else the fixed +-72 bits of rounds 2-3; quad: the
+    parabola probe (measured, not kept: longer tail); fill: probe candidates that clamp onto each other are replaced by the nearest
+    uncosted neighbours (round 4, kept)"""
     extra = getattr(curve, "extra", None) if tight else None
     known = {}
     st = {"fit_hi": -1, "fail_lo": 1 << 20, "gl": None, "gh": None}
@@ -198,6 +200,11 @@ def run(curve, start, policy, hint=None, tight=True, quad=False, qd=(2, 1), rnd=
                 for g in (ge, ge + d, ge - d):
                     g = min(max(g, gl + 1), gh - 1)
                     if g not in cand: cand.append(g)
+                k = 1
+                while fill and len(cand) < NC and k < w:      # candidates that clamped onto each other: the nearest uncosted neighbours instead
+                    for g in (ge - k, ge + k):
+                        if gl < g < gh and g not in cand and len(cand) < NC: cand.append(g)
+                    k += 1
                 probes_done += 1
         if policy == "probe" and not cand and first and cold and hint is not None:
             g0 = min(max(hint, 8), 1000)
