@@ -1393,7 +1393,12 @@ int ac3mi_transcode_batch(ac3mi_ctx *ctx, const ac3mi_decode_desc *dec, const ac
     if (split) { const int r = ensure_split(ctx, nfr); if (r != AC3MI_OK) return r; }
     // Decoder front end, transform to s16, encoder: back to back on the context's stream.  (Until round 2 two chunks were
     // pipelined over two streams; profiles/transcode_overlap.py measured 12.20 ms with and 12.23 - 12.27 ms without it per
-    // 65 536 cold frames, and the sum of the separate decode-to-s16 and encode calls at 12.1 - 12.2 ms: no overlap to keep.)
+    // 65 536 cold frames, and the sum of the separate decode-to-s16 and encode calls at 12.1 - 12.2 ms: no overlap to keep.
+    // Round 4 tried it for MID-SIZE calls, where the one-wavefront-per-stream kernels take their single-wavefront latency of
+    // 90 - 140 us whatever the batch: chunks of 2 048 streams on two HIP streams, one chunk's encoder beside the next one's
+    // decoder - 3 072 / 4 096 / 8 192 / 16 384 streams 0.561 / 0.644 / 1.265 / 2.175 ms against 0.537 / 0.639 / 1.142 / 2.110
+    // in one piece: a kernel of 2 048 frames already occupies every CU (the six-wavefront-per-frame kernels) or is dispatched
+    // whole before the other stream's (the others), so the chunks' latency floors add up instead of overlapping.)
     const int n_chunks = 1;
     auto chunk_lo = [&](int k) { return (int)((long long)n_streams * k / n_chunks); };
     auto front = [&](int k) -> hipError_t {

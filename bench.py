@@ -418,7 +418,7 @@ def secondary_timings(pkg, eng, dev, C, rank, dist, barrier, steps=20, checks=Tr
     return res
 
 
-def per_stream_curve(eng, C, sizes=(1, 64, 512, 2048, 8192, 65536), passes=8):
+def per_stream_curve(eng, C, sizes=(1, 64, 512, 2048, 4096, 8192, 65536), passes=8):
     """north_star: ">= 50x realtime per stream".  One frame is 32 ms of audio, so a stream runs at 32 ms / (time of the round
     that advances it by a frame): rounds of S one-frame streams through ac3mi_transcode_batch, each round from fresh stream
     state (reset outside the timer), HIP events on the engine's stream.  Small rounds take the fused decoder and the block
