@@ -362,8 +362,10 @@ __device__ void bit_allocate_wave(const LDS &L, int16_t *bmask, const BaCtx &c, 
     // S3: leaks
     const int seed = start == 0 ? bA - 1 : bndstart;
     const bool in = live && b >= seed;
-    int fast = wave_incl_scan_min(in ? psd + c.fgain - b * c.fdecay : INF) + b * c.fdecay;
-    int slow = wave_incl_scan_min(in ? psd + c.sgain - b * c.sdecay : INF) + b * c.sdecay;
+    int fast = in ? psd + c.fgain - b * c.fdecay : INF, slow = in ? psd + c.sgain - b * c.sdecay : INF;
+    wave_incl_scan_min2(fast, slow);                    // (two scans interleaved, wave_ops.h)
+    fast += b * c.fdecay;
+    slow += b * c.sdecay;
     if (start != 0) {
         const int ff = c.fast + (b - bndstart + 1) * c.fdecay, sl = c.slow + (b - bndstart + 1) * c.sdecay;
         fast = ff < fast ? ff : fast;
@@ -478,8 +480,10 @@ __device__ void bit_allocate_finish(const LDS &L, int16_t *bmask, const BaCtx &c
     // S3: leaks
     const int seed = start == 0 ? bA - 1 : bndstart;
     const bool in = live && b >= seed;
-    int fast = wave_incl_scan_min(in ? psd + c.fgain - b * c.fdecay : INF) + b * c.fdecay;
-    int slow = wave_incl_scan_min(in ? psd + c.sgain - b * c.sdecay : INF) + b * c.sdecay;
+    int fast = in ? psd + c.fgain - b * c.fdecay : INF, slow = in ? psd + c.sgain - b * c.sdecay : INF;
+    wave_incl_scan_min2(fast, slow);                    // (two scans interleaved, wave_ops.h)
+    fast += b * c.fdecay;
+    slow += b * c.sdecay;
     if (start != 0) {
         const int ff = c.fast + (b - bndstart + 1) * c.fdecay, sl = c.slow + (b - bndstart + 1) * c.sdecay;
         fast = ff < fast ? ff : fast;

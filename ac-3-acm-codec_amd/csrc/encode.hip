@@ -221,8 +221,10 @@ __device__ void mask_row_wave(const MaskTabs &T, int16_t *bndpsd, int bndend, bo
     const unsigned long long sm = __ballot(stop);
     const int begin = sm ? __builtin_ctzll(sm) + 1 : 7;
     const bool live = b >= begin - 1 && b < bndend;
-    const int fast = wave_incl_scan_max(live ? cur - fgain + b * fdecay : NEG) - b * fdecay;
-    const int slow = wave_incl_scan_max(live ? cur - sgain + b * sdecay : NEG) - b * sdecay;
+    int fast = live ? cur - fgain + b * fdecay : NEG, slow = live ? cur - sgain + b * sdecay : NEG;
+    wave_incl_scan_max2(fast, slow);                    // (two scans interleaved, wave_ops.h)
+    fast -= b * fdecay;
+    slow -= b * sdecay;
     int excite;
     if (b < begin) excite = (int16_t)(cur - fgain - lowcomp);
     else if (b < 22) { const int v = fast - lowcomp; excite = (int16_t)(slow > v ? slow : v); }

@@ -35,42 +35,60 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
     return wave_last(v);
 }
 
-// maximum of all lanes' non-negative values, wave-uniform
-__device__ __forceinline__ int wave_max_nonneg(int v)
-{
-#define AC3MI_STEP(ctrl, rows, bc) { const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, bc); v = t > v ? t : v; }
-    AC3MI_STEP(0x111, 0xf, true) AC3MI_STEP(0x112, 0xf, true) AC3MI_STEP(0x114, 0xf, true) AC3MI_STEP(0x118, 0xf, true)
-    AC3MI_STEP(0x142, 0xa, false) AC3MI_STEP(0x143, 0xc, false)
-#undef AC3MI_STEP
-    return __builtin_amdgcn_readlane(v, 63);
-}
+// Prefix minimum / maximum.  One `v_max_i32_dpp v, v, v` per step: a lane whose source lies outside its row (or whose row is
+// masked out) is left unwritten, which IS the identity - no identity register, no separate move.  hipcc does not form this
+// from __builtin_amdgcn_update_dpp + max (it emits v_mov_b32 identity, s_nop, v_mov_b32_dpp, v_max: four instructions per
+// step), so the steps are spelled out; `s_nop 1` = the two wait states a DPP read needs behind the VALU write of its source
+// (gfx9 data hazard), which the compiler cannot place inside an asm block - nor behind it, hence the trailing one.
+#define AC3MI_DPP6(op) \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+    "s_nop 1"
+// two independent scans interleaved: each fills one of the other's wait states
+#define AC3MI_DPP6x2(op) \
+    "s_nop 1\n\t" \
+    op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" op " %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t" \
+    op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" op " %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t" \
+    op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" op " %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t" \
+    op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" op " %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t" \
+    op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" op " %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0\n\t" \
+    op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" op " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
 
-// prefix minimum / maximum (lanes shifted in from outside a row keep the identity)
 __device__ __forceinline__ int wave_incl_scan_min(int v)
 {
-    constexpr int ID = 0x3fffffff;
-#define AC3MI_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, rows, 0xf, false); v = t < v ? t : v; }
-    AC3MI_STEP(0x111, 0xf) AC3MI_STEP(0x112, 0xf) AC3MI_STEP(0x114, 0xf) AC3MI_STEP(0x118, 0xf)
-    AC3MI_STEP(0x142, 0xa) AC3MI_STEP(0x143, 0xc)
-#undef AC3MI_STEP
+    asm volatile(AC3MI_DPP6("v_min_i32_dpp") : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int wave_incl_scan_max(int v)
 {
-    constexpr int ID = -0x3fffffff;
-#define AC3MI_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, rows, 0xf, false); v = t > v ? t : v; }
-    AC3MI_STEP(0x111, 0xf) AC3MI_STEP(0x112, 0xf) AC3MI_STEP(0x114, 0xf) AC3MI_STEP(0x118, 0xf)
-    AC3MI_STEP(0x142, 0xa) AC3MI_STEP(0x143, 0xc)
-#undef AC3MI_STEP
+    asm volatile(AC3MI_DPP6("v_max_i32_dpp") : "+v"(v));
     return v;
 }
+__device__ __forceinline__ void wave_incl_scan_min2(int &a, int &b)
+{
+    asm volatile(AC3MI_DPP6x2("v_min_i32_dpp") : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wave_incl_scan_max2(int &a, int &b)
+{
+    asm volatile(AC3MI_DPP6x2("v_max_i32_dpp") : "+v"(a), "+v"(b));
+}
+
+// maximum of all lanes' non-negative values, wave-uniform
+__device__ __forceinline__ int wave_max_nonneg(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_max(v), 63); }
+
 // suffix minimum: lane i gets min over lanes i..63 (row_shl inside the rows, the row totals through scalars)
 __device__ __forceinline__ int wave_suffix_scan_min(int v, int lane)
 {
     constexpr int ID = 0x3fffffff;
-#define AC3MI_STEP(ctrl) { const int t = __builtin_amdgcn_update_dpp(ID, v, ctrl, 0xf, 0xf, false); v = t < v ? t : v; }
-    AC3MI_STEP(0x101) AC3MI_STEP(0x102) AC3MI_STEP(0x104) AC3MI_STEP(0x108)
-#undef AC3MI_STEP
+    asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
     const int t1 = __builtin_amdgcn_readlane(v, 16), t2 = __builtin_amdgcn_readlane(v, 32), t3 = __builtin_amdgcn_readlane(v, 48);
     const int a2 = t2 < t3 ? t2 : t3, a1 = t1 < a2 ? t1 : a2;
     const int r = lane >> 4;
