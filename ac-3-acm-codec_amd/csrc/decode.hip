@@ -103,10 +103,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
     st.chincpl = st.phsflginu = st.cplstrtmant = st.cplendmant = st.ncplbnd = st.cplstrtbnd = 0;
     st.cplbndstrc = 0;
     st.rematflg = 0;
-    for (int i = 0; i < 5; i++) st.endmant[i] = 0;
+    st.ends = 7ull << 40;
     st.bai = st.csnroffst = 0;
-    for (int i = 0; i < 7; i++) st.cbai[i] = 0;
-    for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
+    st.cbai8 = 0;
+    st.deltbae2 = 0xaaau;
     st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
     DK_DECL();
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 if (st.lfeon && (P.req_flags & AC3MI_LFE)) st.output |= AC3MI_LFE;
                 st.dynrng = st.level = level * 2;
                 st.dynrnge = P.dynrng_on;
-                for (int i = 0; i < 6; i++) st.deltbae[i] = 2;
+                st.deltbae2 = 0xaaau;
                 int twice = !acmod;
                 do {
                     rd.get(5);
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                         st.cplstrtbnd = k_cpl_bnd0[begf];
                         st.cplstrtmant = begf * 12 + 37;
                         st.cplendmant = endf * 12 + 73;
+                        st.set_endm(6, st.cplendmant);
                         st.cplbndstrc = 0;
                         for (int i = 0; i < nsub - 1; i++)
                             if (rd.get(1)) { st.cplbndstrc |= 1u << i; st.ncplbnd--; }
@@ -307,11 +308,11 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
 #pragma unroll
                 for (int i = 0; i < 5; i++)
                     if (i < nf && !err && ((chexp >> (2 * i)) & 3)) {
-                        if ((st.chincpl >> i) & 1) st.endmant[i] = st.cplstrtmant;
+                        if ((st.chincpl >> i) & 1) st.set_endm(i, st.cplstrtmant);
                         else {
                             const int bw = rd.get(6);
                             if (bw > 60) err = 1;
-                            else st.endmant[i] = bw * 3 + 73;
+                            else st.set_endm(i, bw * 3 + 73);
                         }
                     }
                 if (err) break;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 for (int i = 0; i < 5; i++) {
                     const int es = (chexp >> (2 * i)) & 3;
                     if (i < nf && !err && es) {
-                        const int gs = 3 << (es - 1), ngrp = (st.endmant[i] + gs - 4) / gs;
+                        const int gs = 3 << (es - 1), ngrp = (st.endm(i) + gs - 4) / gs;
                         redo |= 1 << i;
                         const int e0 = rd.get(4);
                         if (lane == 0) L.exp[row_off(i)] = (uint8_t)e0;
@@ -356,10 +357,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 if (rd.get(1)) {
                     redo = 127;
                     st.csnroffst = rd.get(6);
-                    if (st.chincpl) st.cbai[6] = rd.get(7);
+                    if (st.chincpl) st.set_cbai(6, rd.get(7));
 #pragma unroll
-                    for (int i = 0; i < 5; i++) if (i < nf) st.cbai[i] = rd.get(7);
-                    if (st.lfeon) st.cbai[5] = rd.get(7);
+                    for (int i = 0; i < 5; i++) if (i < nf) st.set_cbai(i, rd.get(7));
+                    if (st.lfeon) st.set_cbai(5, rd.get(7));
                 } else if (blk == 0) reuse0 = true;
                 if (st.chincpl) {
                     if (rd.get(1)) {
@@ -370,15 +371,15 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 }
                 if (rd.get(1)) {                                            // deltbaie
                     redo = 127;
-                    if (st.chincpl) st.deltbae[5] = rd.get(2);
+                    if (st.chincpl) st.set_deltbae(5, rd.get(2));
 #pragma unroll
-                    for (int i = 0; i < 5; i++) if (i < nf) st.deltbae[i] = rd.get(2);
+                    for (int i = 0; i < 5; i++) if (i < nf) st.set_deltbae(i, rd.get(2));
 #pragma unroll
                     for (int pass = 0; pass < 6; pass++) {
                         const int slot = pass == 0 ? 5 : pass - 1;          // cpl first, then fbw (parse.c:763-771)
                         if (err || pass > nf) continue;
                         if (slot == 5 && !st.chincpl) continue;
-                        if (st.deltbae[slot] != 1) continue;
+                        if (st.deltbae(slot) != 1) continue;
                         // parse_deltba: parse.c:272-294
                         if (lane < 50) L.deltba[slot][lane] = 0;
                         int nseg = rd.get(3), band = 0;
@@ -400,10 +401,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
 
                 // ---- bit allocation: parse.c:774-798 ----
                 if (redo) {
-                    bool allzero = !st.csnroffst && !(st.chincpl && (st.cbai[6] >> 3)) && !(st.lfeon && (st.cbai[5] >> 3));
+                    bool allzero = !st.csnroffst && !(st.chincpl && (st.cbai(6) >> 3)) && !(st.lfeon && (st.cbai(5) >> 3));
 #pragma unroll
                     for (int i = 0; i < 5; i++)
-                        if (i < nf && (st.cbai[i] >> 3)) allzero = false;
+                        if (i < nf && (st.cbai(i) >> 3)) allzero = false;
                     dirty_bap |= allzero ? 0x7f : redo;
                     if (PARSE && lane < 7 && (allzero || ((redo >> lane) & 1))) L.tot[lane][2] = 0;
                     if (allzero) {
@@ -411,11 +412,10 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     } else {
                         // the channel slots that need a new allocation, two per sweep of the band PSDs (wave-uniform; written
                         // out rather than as lambdas over `st`: a closure that holds its address keeps the whole state in scratch)
-#define AC3MI_SLOT_END(slot) ((slot) == 0 ? st.endmant[0] : (slot) == 1 ? st.endmant[1] : (slot) == 2 ? st.endmant[2] : (slot) == 3 ? st.endmant[3] \
-                              : (slot) == 4 ? st.endmant[4] : (slot) == 5 ? 7 : st.cplendmant)
+#define AC3MI_SLOT_END(slot) st.endm(slot)
                         int todo = redo & (((1 << nf) - 1) | (st.lfeon ? 32 : 0) | (st.chincpl ? 64 : 0));
 #pragma unroll
-                        for (int i = 0; i < 5; i++) if (st.endmant[i] <= 0) todo &= ~(1 << i);
+                        for (int i = 0; i < 5; i++) if (st.endm(i) <= 0) todo &= ~(1 << i);
                         if (st.cplendmant <= st.cplstrtmant) todo &= ~64;
                         while (todo) {
                             const int sA = __builtin_ctz(todo);
@@ -428,10 +428,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                             const int wide = ba_wide_psd(L, ba_lo0, ba_hi0, L.exp + row_off(sA), stA, enA, L.exp + row_off(sB), stB, enB, two, lane);
                             for (int h = 0; h < (two ? 2 : 1); h++) {          // (one call site: the routine is inlined once)
                                 const int slot = h ? sB : sA, start = h ? stB : stA, end = h ? enB : enA;
-                                const int mybai = slot == 0 ? st.cbai[0] : slot == 1 ? st.cbai[1] : slot == 2 ? st.cbai[2] : slot == 3 ? st.cbai[3]
-                                                : slot == 4 ? st.cbai[4] : slot == 5 ? st.cbai[5] : st.cbai[6];
-                                const int mydeltbae = slot == 0 ? st.deltbae[0] : slot == 1 ? st.deltbae[1] : slot == 2 ? st.deltbae[2] : slot == 3 ? st.deltbae[3]
-                                                    : slot == 4 ? st.deltbae[4] : slot == 5 ? 2 : st.deltbae[5];
+                                const int mybai = st.cbai(slot);
+                                const int mydeltbae = slot == 5 ? 2 : st.deltbae(slot == 6 ? 5 : slot);
                                 BaCtx c;
                                 c.halfrate = st.halfrate;
                                 c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     B.chincpl = st.chincpl; B.dithmask = dithmask; B.rematflg = st.rematflg;
                     B.cplstrtmant = st.cplstrtmant; B.cplendmant = st.cplendmant;
 #pragma unroll
-                    for (int i = 0; i < 5; i++) { B.endmant[i] = st.endmant[i]; B.gain[i] = gain[i]; }
+                    for (int i = 0; i < 5; i++) { B.endmant[i] = st.endm(i); B.gain[i] = gain[i]; }
                     B.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
                     const uint32_t lfsr_i0 = P.lfsr_idx[st.lfsr];
                     const bool lfsr_live = st.lfsr != 0;
@@ -513,8 +511,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     const int k = lane;
                     const int slot_l = st.chincpl ? (k <= cplfirst ? k : k == cplfirst + 1 ? 6 : k - 1 < nf ? k - 1 : 5) : (k < nf ? k : 5);
                     const bool seg_l = k < nseg;
-                    const int end_l = slot_l == 0 ? st.endmant[0] : slot_l == 1 ? st.endmant[1] : slot_l == 2 ? st.endmant[2] : slot_l == 3 ? st.endmant[3]
-                                    : slot_l == 4 ? st.endmant[4] : slot_l == 5 ? 7 : st.cplendmant;
+                    const int end_l = (int)((uint32_t)(st.ends >> (8 * slot_l)) & 0xffu);
                     const int start_l = slot_l == 6 ? st.cplstrtmant : 0;
                     const int mult_l = slot_l < 5 ? (dithmask >> slot_l) & 1 : slot_l == 6 ? ncpl_dith : 0;
                     const uint32_t key_l = 0x80000000u | (uint32_t)start_l | ((uint32_t)end_l << 10);
@@ -572,15 +569,14 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                         const uint32_t fl = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg << 24);
                         const uint32_t w0 = lane == 0 ? rd.pos() : lane == 1 ? frame_draws : lane == 2 ? fl : st.cplbndstrc;
                         if (lane < 4) reinterpret_cast<uint32_t *>(dp)[lane] = w0;
-                        const int em = lane == 0 ? st.endmant[0] : lane == 1 ? st.endmant[1] : lane == 2 ? st.endmant[2] : lane == 3 ? st.endmant[3]
-                                     : lane == 4 ? st.endmant[4] : lane == 5 ? st.cplstrtmant : st.cplendmant;
+                        const int em = lane == 5 ? st.cplstrtmant : (int)((uint32_t)(st.ends >> (8 * (lane & 7))) & 0xffu);
                         if (lane < 7) reinterpret_cast<uint16_t *>(dp + 16)[lane] = (uint16_t)em;
                         if (lane < 8) { dp[32 + lane] = (uint8_t)rv_exp; dp[40 + lane] = (uint8_t)rv_bap; }
                         const float gl = lane == 0 ? gain[0] : lane == 1 ? gain[1] : lane == 2 ? gain[2] : lane == 3 ? gain[3] : lane == 4 ? gain[4]
                                        : (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
                         // spare word: the frame's own SNR offsets, 16 csnroffst + fsnroffst of channel 0 - a transcode's encoder starts
                         // costing its search there (a hint: which offsets are costed never changes a result, encode.hip)
-                        const uint32_t w12 = lane < 6 ? __float_as_uint(gl) : (uint32_t)(16 * st.csnroffst + (st.cbai[0] >> 3));
+                        const uint32_t w12 = lane < 6 ? __float_as_uint(gl) : (uint32_t)(16 * st.csnroffst + (st.cbai(0) >> 3));
                         if (lane < 7) reinterpret_cast<uint32_t *>(dp + 48)[lane] = w12;
                     }
                     bd_ok = true;

@@ -122,10 +122,18 @@ struct St {
     int chincpl, phsflginu, cplstrtmant, cplendmant, ncplbnd, cplstrtbnd;
     uint32_t cplbndstrc;
     int rematflg;
-    int endmant[5];
+    // per-slot values packed (round 4: the parse kernel spills scalar registers by the hundred; eighteen of them were these
+    // three arrays, and a slot picked at run time is now a shift instead of a chain of selects)
+    uint64_t ends;          // byte k: end of slot k's mantissas - 0..4 the full-bandwidth channels' endmant, 5: 7 (LFE), 6: cplendmant
     int bai, csnroffst;
-    int cbai[7];            // per-slot fsnroffst<<3 | fgaincod
-    int deltbae[6];         // 0..4 fbw, 5 = cpl
+    uint64_t cbai8;         // byte k: slot k's fsnroffst << 3 | fgaincod (0..4 fbw, 5 lfe, 6 cpl)
+    uint32_t deltbae2;      // 2 bits per slot: 0..4 fbw, 5 = cpl
+    __device__ __forceinline__ int endm(int k) const { return (int)((uint32_t)(ends >> (8 * k)) & 0xffu); }
+    __device__ __forceinline__ void set_endm(int k, int v) { ends = (ends & ~(0xffull << (8 * k))) | ((uint64_t)(uint32_t)v << (8 * k)); }
+    __device__ __forceinline__ int cbai(int k) const { return (int)((uint32_t)(cbai8 >> (8 * k)) & 0xffu); }
+    __device__ __forceinline__ void set_cbai(int k, int v) { cbai8 = (cbai8 & ~(0xffull << (8 * k))) | ((uint64_t)(uint32_t)v << (8 * k)); }
+    __device__ __forceinline__ int deltbae(int k) const { return (int)((deltbae2 >> (2 * k)) & 3u); }
+    __device__ __forceinline__ void set_deltbae(int k, int v) { deltbae2 = (deltbae2 & ~(3u << (2 * k))) | ((uint32_t)v << (2 * k)); }
     int cplfleak, cplsleak;
     uint32_t lfsr;
 };
