@@ -95,19 +95,17 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
     ba_lane_band(L, lane, ba_lo0, ba_hi0);
 
     St st;
-    st.fscod = st.halfrate = st.acmod = st.lfeon = 0;
+    st.acmod = st.lfeon = 0;
     st.nf = 0;
+    st.cfg = 1u << 4;                   // dynrnge 1, the rest 0
+    st.cplw = 0;
     st.clev = st.slev = st.level = st.dynrng = 0.f;
     st.output = 0;
-    st.dynrnge = 1;
-    st.chincpl = st.phsflginu = st.cplstrtmant = st.cplendmant = st.ncplbnd = st.cplstrtbnd = 0;
+    st.chincpl = st.cplstrtmant = 0;
     st.cplbndstrc = 0;
-    st.rematflg = 0;
     st.ends = 7ull << 40;
-    st.bai = st.csnroffst = 0;
     st.cbai8 = 0;
     st.deltbae2 = 0xaaau;
-    st.cplfleak = st.cplsleak = 0;
     const int sslot = P.slot ? P.slot[s] : s;
     DK_DECL();
     st.lfsr = (MODE == 0 || MODE == 4) ? (uint32_t)P.lfsr_state[sslot] : 1u;
@@ -170,13 +168,13 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
             if (b5 >= 0x60) hdr_ok = false;
             if ((b4 & 63) >= 38 || (b4 & 0xc0) == 0xc0) hdr_ok = false;
             if (hdr_ok) {
-                st.fscod = b4 >> 6;
+                st.set_fscod(b4 >> 6);
                 const int bsid = b5 >> 3;
-                st.halfrate = bsid < 9 ? 0 : bsid - 8;
+                st.set_halfrate(bsid < 9 ? 0 : bsid - 8);
                 st.acmod = b6 >> 5;
                 if (st.acmod != P.acmod) hdr_ok = false;
                 const int code = b4 & 63, rate = k_kbps[code >> 1];
-                const int fbytes = st.fscod == 0 ? 4 * rate : st.fscod == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
+                const int fbytes = st.fscod() == 0 ? 4 * rate : st.fscod() == 1 ? 2 * (320 * rate / 147 + (code & 1)) : 6 * rate;
                 if (fbytes > P.frame_bytes) hdr_ok = false;        // frame_bytes = the largest frame of the batch (44.1 kHz alternates)
             }
         }
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
             if (hdr_ok) {
                 if (st.lfeon && (P.req_flags & AC3MI_LFE)) st.output |= AC3MI_LFE;
                 st.dynrng = st.level = level * 2;
-                st.dynrnge = P.dynrng_on;
+                st.set_dynrnge(P.dynrng_on ? 1 : 0);
                 st.deltbae2 = 0xaaau;
                 int twice = !acmod;
                 do {
@@ -212,9 +210,9 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     do rd.get(8); while (len--);
                 }
                 st.nf = k_nfchans[st.acmod];
-                if (hth_fscod != st.fscod) {
-                    if (lane < 50) L.hth[lane] = P.tab->hth[st.fscod][lane];
-                    hth_fscod = st.fscod;
+                if (hth_fscod != st.fscod()) {
+                    if (lane < 50) L.hth[lane] = P.tab->hth[st.fscod()][lane];
+                    hth_fscod = st.fscod();
                 }
                 status |= (uint32_t)st.output << 16;
             }
@@ -241,7 +239,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 do {
                     if (rd.get(1)) {
                         const int code = rd.sget(8);
-                        if (st.dynrnge) st.dynrng = st.level * dynrng_range(P, code, (fidx * 6 + blk) * 2 + word, lane);
+                        if (st.dynrnge()) st.dynrng = st.level * dynrng_range(P, code, (fidx * 6 + blk) * 2 + word, lane);
                     }
                     word++;
                 } while (twice--);
@@ -251,18 +249,18 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     if (rd.get(1)) {                                        // cplinu
                         st.chincpl = (int)(__builtin_bitreverse32(rd.get(nf)) >> (32 - nf));
                         if (st.acmod < 2) { err = 1; break; }
-                        if (st.acmod == 2) st.phsflginu = rd.get(1);
+                        if (st.acmod == 2) st.set_phsflginu(rd.get(1));
                         const int begf = rd.get(4), endf = rd.get(4);
                         if (endf + 3 - begf < 0) { err = 1; break; }
                         const int nsub = endf + 3 - begf;
-                        st.ncplbnd = nsub;
-                        st.cplstrtbnd = k_cpl_bnd0[begf];
+                        int ncplbnd = nsub;
+                        st.set_cplstrtbnd(k_cpl_bnd0[begf]);
                         st.cplstrtmant = begf * 12 + 37;
-                        st.cplendmant = endf * 12 + 73;
-                        st.set_endm(6, st.cplendmant);
+                        st.set_endm(6, endf * 12 + 73);
                         st.cplbndstrc = 0;
                         for (int i = 0; i < nsub - 1; i++)
-                            if (rd.get(1)) { st.cplbndstrc |= 1u << i; st.ncplbnd--; }
+                            if (rd.get(1)) { st.cplbndstrc |= 1u << i; ncplbnd--; }
+                        st.set_ncplbnd(ncplbnd);
                     }
                 } else if (blk == 0) reuse0 = true;
                 if (st.chincpl) {                                           // coupling coordinates
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                             if (rd.get(1)) {
                                 const int master = 3 * rd.get(2);
                                 any = 1;
-                                for (int j = 0; j < st.ncplbnd; j++) {
+                                for (int j = 0, nb = st.ncplbnd(); j < nb; j++) {
                                     const int ex = rd.get(4);
                                     int ma = rd.get(4);
                                     ma = (ex == 15) ? (ma << 14) : ((ma | 0x10) << 13);
@@ -281,16 +279,17 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                                 }
                             } else if (blk == 0) reuse0 = true;
                         }
-                    if (st.acmod == 2 && st.phsflginu && any)
-                        for (int j = 0; j < st.ncplbnd; j++)
+                    if (st.acmod == 2 && st.phsflginu() && any)
+                        for (int j = 0, nb = st.ncplbnd(); j < nb; j++)
                             if (rd.get(1) && lane == 0) L.cplco[1][j] = -L.cplco[1][j];
                 }
                 if (st.acmod == 2) {
                     if (rd.get(1)) {                                        // rematstr
                         const int end = st.chincpl ? st.cplstrtmant : 253;
                         int i = 0;
-                        st.rematflg = 0;
-                        do st.rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                        int rematflg = 0;
+                        do rematflg |= rd.get(1) << i; while (k_remat_edge[1 + i++] < end);
+                        st.set_rematflg(rematflg);
                     } else if (blk == 0) reuse0 = true;
                 }
                 int cplexpstr = 0, lfeexpstr = 0, chexp = 0;   // chexp: 2 bits per channel
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 // ---- exponents: parse.c:703-736 ----
                 int redo = 0;
                 if (cplexpstr) {
-                    const int ngrp = (st.cplendmant - st.cplstrtmant) / (3 << (cplexpstr - 1));
+                    const int ngrp = (st.cplendmant() - st.cplstrtmant) / (3 << (cplexpstr - 1));
                     const int e0 = rd.get(4) << 1;
                     redo = 64;
                     if (read_exponents(FB, rd.pos(), cplexpstr, ngrp, e0, L.exp + row_off(6) + st.cplstrtmant, lane)) { err = 1; break; }
@@ -352,11 +351,11 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 DK_LAP(2);
                 dirty_exp |= redo;                                          // (bits: 0..4 fbw, 5 lfe, 6 coupling channel)
                 // ---- bit-allocation parameters: parse.c:738-772 ----
-                if (rd.get(1)) { redo = 127; st.bai = rd.get(11); }
+                if (rd.get(1)) { redo = 127; st.set_bai(rd.get(11)); }
                 else if (blk == 0) reuse0 = true;
                 if (rd.get(1)) {
                     redo = 127;
-                    st.csnroffst = rd.get(6);
+                    st.set_csnroffst(rd.get(6));
                     if (st.chincpl) st.set_cbai(6, rd.get(7));
 #pragma unroll
                     for (int i = 0; i < 5; i++) if (i < nf) st.set_cbai(i, rd.get(7));
@@ -365,8 +364,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 if (st.chincpl) {
                     if (rd.get(1)) {
                         redo |= 64;
-                        st.cplfleak = 9 - rd.get(3);
-                        st.cplsleak = 9 - rd.get(3);
+                        st.set_cplfleak(9 - rd.get(3));
+                        st.set_cplsleak(9 - rd.get(3));
                     } else if (blk == 0) reuse0 = true;
                 }
                 if (rd.get(1)) {                                            // deltbaie
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
 
                 // ---- bit allocation: parse.c:774-798 ----
                 if (redo) {
-                    bool allzero = !st.csnroffst && !(st.chincpl && (st.cbai(6) >> 3)) && !(st.lfeon && (st.cbai(5) >> 3));
+                    bool allzero = !st.csnroffst() && !(st.chincpl && (st.cbai(6) >> 3)) && !(st.lfeon && (st.cbai(5) >> 3));
 #pragma unroll
                     for (int i = 0; i < 5; i++)
                         if (i < nf && (st.cbai(i) >> 3)) allzero = false;
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                         int todo = redo & (((1 << nf) - 1) | (st.lfeon ? 32 : 0) | (st.chincpl ? 64 : 0));
 #pragma unroll
                         for (int i = 0; i < 5; i++) if (st.endm(i) <= 0) todo &= ~(1 << i);
-                        if (st.cplendmant <= st.cplstrtmant) todo &= ~64;
+                        if (st.cplendmant() <= st.cplstrtmant) todo &= ~64;
                         while (todo) {
                             const int sA = __builtin_ctz(todo);
                             todo &= todo - 1;
@@ -431,20 +430,21 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                                 const int mybai = st.cbai(slot);
                                 const int mydeltbae = slot == 5 ? 2 : st.deltbae(slot == 6 ? 5 : slot);
                                 BaCtx c;
-                                c.halfrate = st.halfrate;
-                                c.fdecay = (63 + 20 * ((st.bai >> 7) & 3)) >> c.halfrate;
+                                const int bai = st.bai();
+                                c.halfrate = st.halfrate();
+                                c.fdecay = (63 + 20 * ((bai >> 7) & 3)) >> c.halfrate;
                                 c.fgain = 128 + 128 * (mybai & 7);
-                                c.sdecay = (15 + 2 * (st.bai >> 9)) >> c.halfrate;
-                                c.sgain = k_slowgain[(st.bai >> 5) & 3];
-                                c.dbknee = k_dbpb[(st.bai >> 3) & 3];
+                                c.sdecay = (15 + 2 * (bai >> 9)) >> c.halfrate;
+                                c.sgain = k_slowgain[(bai >> 5) & 3];
+                                c.dbknee = k_dbpb[(bai >> 3) & 3];
                                 c.hth = L.hth;
                                 c.deltba = (mydeltbae == 2) ? nullptr : L.deltba[slot == 6 ? 5 : slot];
-                                const int fl = k_floors[st.bai & 7];
-                                c.snroffset = 960 - 64 * st.csnroffst - 4 * (mybai >> 3) + fl;
+                                const int fl = k_floors[bai & 7];
+                                c.snroffset = 960 - 64 * st.csnroffst() - 4 * (mybai >> 3) + fl;
                                 c.floor = fl >> 5;
-                                c.fast = slot == 6 ? st.cplfleak << 8 : 0;
-                                c.slow = slot == 6 ? st.cplsleak << 8 : 0;
-                                bit_allocate_finish(L, L.bmask, c, slot == 6 ? st.cplstrtbnd : 0, start, end, L.exp + row_off(slot), L.bap + row_off(slot), wide, h, lane);
+                                c.fast = slot == 6 ? st.cplfleak() << 8 : 0;
+                                c.slow = slot == 6 ? st.cplsleak() << 8 : 0;
+                                bit_allocate_finish(L, L.bmask, c, slot == 6 ? st.cplstrtbnd() : 0, start, end, L.exp + row_off(slot), L.bap + row_off(slot), wide, h, lane);
                             }
                         }
 #undef AC3MI_SLOT_END
@@ -487,8 +487,8 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                 if constexpr (!PARSE) {
                     MantBlk B;
                     B.nf = nf; B.lfeon = st.lfeon; B.acmod = st.acmod; B.in_lfe = in_lfe;
-                    B.chincpl = st.chincpl; B.dithmask = dithmask; B.rematflg = st.rematflg;
-                    B.cplstrtmant = st.cplstrtmant; B.cplendmant = st.cplendmant;
+                    B.chincpl = st.chincpl; B.dithmask = dithmask; B.rematflg = st.rematflg();
+                    B.cplstrtmant = st.cplstrtmant; B.cplendmant = st.cplendmant();
 #pragma unroll
                     for (int i = 0; i < 5; i++) { B.endmant[i] = st.endm(i); B.gain[i] = gain[i]; }
                     B.lfe_gain = (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                     // the descriptor, straight from the lanes (BlkDesc's layout)
                     {
                         uint8_t *dp = reinterpret_cast<uint8_t *>(P.desc + (fidx * 6 + blk));
-                        const uint32_t fl = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg << 24);
+                        const uint32_t fl = ((uint32_t)st.chincpl << 8) | ((uint32_t)dithmask << 16) | ((uint32_t)st.rematflg() << 24);
                         const uint32_t w0 = lane == 0 ? rd.pos() : lane == 1 ? frame_draws : lane == 2 ? fl : st.cplbndstrc;
                         if (lane < 4) reinterpret_cast<uint32_t *>(dp)[lane] = w0;
                         const int em = lane == 5 ? st.cplstrtmant : (int)((uint32_t)(st.ends >> (8 * (lane & 7))) & 0xffu);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64, MODE >= 4 ? DEC_LBP : DEC_LB0) void decode_kern
                                        : (st.output & AC3MI_LFE) ? st.dynrng : 0.f;
                         // spare word: the frame's own SNR offsets, 16 csnroffst + fsnroffst of channel 0 - a transcode's encoder starts
                         // costing its search there (a hint: which offsets are costed never changes a result, encode.hip)
-                        const uint32_t w12 = lane < 6 ? __float_as_uint(gl) : (uint32_t)(16 * st.csnroffst + (st.cbai(0) >> 3));
+                        const uint32_t w12 = lane < 6 ? __float_as_uint(gl) : (uint32_t)(16 * st.csnroffst() + (st.cbai(0) >> 3));
                         if (lane < 7) reinterpret_cast<uint32_t *>(dp + 48)[lane] = w12;
                     }
                     bd_ok = true;

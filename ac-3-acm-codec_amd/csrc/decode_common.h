@@ -116,25 +116,40 @@ __device__ __forceinline__ int surround_level_is_zero(int acmod, int output, flo
 
 // stream-persistent decoder fields (wave-uniform)
 struct St {
-    int fscod, halfrate, acmod, lfeon, nf;
+    int acmod, lfeon, nf;
     float clev, slev, level, bias_unused, dynrng;
-    int output, dynrnge;
-    int chincpl, phsflginu, cplstrtmant, cplendmant, ncplbnd, cplstrtbnd;
+    int output;
+    int chincpl, cplstrtmant;
     uint32_t cplbndstrc;
-    int rematflg;
-    // per-slot values packed (round 4: the parse kernel spills scalar registers by the hundred; eighteen of them were these
-    // three arrays, and a slot picked at run time is now a shift instead of a chain of selects)
+    // Everything else packed (round 4: the parse kernel spills scalar registers by the hundred; these fields were 38 of them,
+    // and a slot picked at run time is now a shift instead of a chain of selects)
     uint64_t ends;          // byte k: end of slot k's mantissas - 0..4 the full-bandwidth channels' endmant, 5: 7 (LFE), 6: cplendmant
-    int bai, csnroffst;
     uint64_t cbai8;         // byte k: slot k's fsnroffst << 3 | fgaincod (0..4 fbw, 5 lfe, 6 cpl)
     uint32_t deltbae2;      // 2 bits per slot: 0..4 fbw, 5 = cpl
+    uint32_t cplw;          // phsflginu 0 | ncplbnd 1-5 | cplstrtbnd 6-11 | cplfleak 12-15 | cplsleak 16-19 | rematflg 20-23
+    uint32_t cfg;           // fscod 0-1 | halfrate 2-3 | dynrnge 4 | bai 5-15 | csnroffst 16-21
     __device__ __forceinline__ int endm(int k) const { return (int)((uint32_t)(ends >> (8 * k)) & 0xffu); }
     __device__ __forceinline__ void set_endm(int k, int v) { ends = (ends & ~(0xffull << (8 * k))) | ((uint64_t)(uint32_t)v << (8 * k)); }
     __device__ __forceinline__ int cbai(int k) const { return (int)((uint32_t)(cbai8 >> (8 * k)) & 0xffu); }
     __device__ __forceinline__ void set_cbai(int k, int v) { cbai8 = (cbai8 & ~(0xffull << (8 * k))) | ((uint64_t)(uint32_t)v << (8 * k)); }
     __device__ __forceinline__ int deltbae(int k) const { return (int)((deltbae2 >> (2 * k)) & 3u); }
     __device__ __forceinline__ void set_deltbae(int k, int v) { deltbae2 = (deltbae2 & ~(3u << (2 * k))) | ((uint32_t)v << (2 * k)); }
-    int cplfleak, cplsleak;
+    __device__ __forceinline__ int cplendmant() const { return endm(6); }
+#define AC3MI_ST_FIELD(name, word, pos, bits) \
+    __device__ __forceinline__ int name() const { return (int)((word >> (pos)) & ((1u << (bits)) - 1u)); } \
+    __device__ __forceinline__ void set_##name(int v) { word = (word & ~(((1u << (bits)) - 1u) << (pos))) | ((uint32_t)v << (pos)); }
+    AC3MI_ST_FIELD(phsflginu, cplw, 0, 1)
+    AC3MI_ST_FIELD(ncplbnd, cplw, 1, 5)
+    AC3MI_ST_FIELD(cplstrtbnd, cplw, 6, 6)
+    AC3MI_ST_FIELD(cplfleak, cplw, 12, 4)
+    AC3MI_ST_FIELD(cplsleak, cplw, 16, 4)
+    AC3MI_ST_FIELD(rematflg, cplw, 20, 4)
+    AC3MI_ST_FIELD(fscod, cfg, 0, 2)
+    AC3MI_ST_FIELD(halfrate, cfg, 2, 2)
+    AC3MI_ST_FIELD(dynrnge, cfg, 4, 1)
+    AC3MI_ST_FIELD(bai, cfg, 5, 11)
+    AC3MI_ST_FIELD(csnroffst, cfg, 16, 6)
+#undef AC3MI_ST_FIELD
     uint32_t lfsr;
 };
 
