@@ -445,14 +445,23 @@ __device__ __forceinline__ int ba_wide_psd(const LDS &L, int lo0, int hi0, const
     const uint32_t sh = (uint32_t)lo & 3u;
 #pragma unroll
     for (int i = 0; i < 6; i++) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-    int psd = (int)(a[0] & 0xffu) << 7;
+    // Bins past the band's width read as exponent 0xef: a neighbour that far down leaves the sum as it is (the difference
+    // clamps to la_neg[255] = 0 and min() keeps psd), so no step needs a test of its own - hipcc had turned `j < w ? nv : psd`
+    // into a compare, two exec-mask instructions and a branch per step.  The sweep runs on psd + 2048 (every exponent byte
+    // + 16: a sum of 24 bins can fall to -23 x 64 below its smallest term), so that |next - psd| is ONE v_sad_u16.
+    int psd = (int)((a[0] & 0xffu) + 16u) << 7;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        int n = w - 4 * i;
+        n = n < 0 ? 0 : n > 4 ? 4 : n;
+        const uint32_t past = n >= 4 ? 0u : 0xffffffffu << (8 * n);
+        a[i] = ((a[i] & ~past) | (0xefefefefu & past)) + 0x10101010u;          // (exponents are 0 .. 24: no carry between bytes)
+    }
     auto step = [&](int j) __attribute__((always_inline)) {
         const int next = (int)((a[j >> 2] >> (8 * (j & 3))) & 0xffu) << 7;
-        const int diff = next - psd;
-        int idx = (diff < 0 ? -diff : diff) >> 1;
+        int idx = (int)(__builtin_amdgcn_sad_u16((uint32_t)next, (uint32_t)psd, 0u) >> 1);      // both in 0 .. 2^15
         idx = idx > 255 ? 255 : idx;
-        const int nv = (next < psd ? next : psd) + L.la_neg[idx];
-        psd = j < w ? nv : psd;
+        psd = (next < psd ? next : psd) + L.la_neg[idx];
     };
     // bands are 3, 6, 12 or 24 bins wide (fewer at a channel's edges)
     if (__any(w > 1)) { step(1); step(2); }
@@ -465,7 +474,7 @@ __device__ __forceinline__ int ba_wide_psd(const LDS &L, int lo0, int hi0, const
 #pragma unroll
         for (int j = 12; j < 24; j++) step(j);
     }
-    return psd;
+    return psd - 2048;
 }
 
 // everything after the band PSDs for one row; `wide` = ba_wide_psd's result, this row's in the lanes of half `half`

@@ -369,10 +369,11 @@ __device__ void exp_stage(const ExpParams &P, ExpLDS &L, size_t fidx, int ch, in
 #pragma unroll
             for (int j = 1; j < 24; j++) {
                 const int pj = 3072 - ((int)((ab[j >> 2] >> (8 * (j & 3))) & 0xffu) << 7);
-                const int c = v - pj;
-                int t = (c >= 0 ? c : -c) >> 1;
+                // |v - pj| in one v_sad_u16 and the larger of the two in one v_max (both are 0 .. 2^15 here: exponents are
+                // 0 .. 24 and a band's sum stays below 3072 + 23 x 64; hipcc spent seven instructions on the two)
+                int t = (int)(__builtin_amdgcn_sad_u16((uint32_t)v, (uint32_t)pj, 0u) >> 1);
                 t = t > 255 ? 255 : t;
-                int nv = (c >= 0 ? v : pj) + (int)L.t.latab[t];
+                int nv = (v > pj ? v : pj) + (int)L.t.latab[t];
                 if (j % 3 == 0) {                                                   // a band may end here
                     const bool ends = j % 12 == 0 ? r12 : j % 6 == 0 ? r6 : r3;
                     if (ends && j < len) mrow[((j / 3) >> lw) - 1] = (int16_t)v;
