@@ -698,6 +698,10 @@ struct MantBlk {
     int chincpl, dithmask, rematflg, cplstrtmant, cplendmant;
     int endmant[5];
     float gain[5], lfe_gain;
+    // mant_block2 (mant2.h) takes a slot's values from these instead - a slot picked at run time is then one shift / one
+    // v_readlane where hipcc built a tree of compares and branches per segment out of `slot == 0 ? gain[0] : ...`:
+    uint64_t ends;          // byte k: endmant[k]
+    float gainv;            // PER LANE: lane k = gain[k] (k < 5), lane 5 = lfe_gain
 };
 
 // segment k of the block in bitstream order -> slot (0..4 fbw, 5 lfe, 6 coupling channel): channel 0, the coupling channel

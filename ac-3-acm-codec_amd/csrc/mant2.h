@@ -158,14 +158,20 @@ __device__ __forceinline__ float dither2(const int16_t *seq, uint32_t i) { retur
 // one dword each (bins 4 lane .. 4 lane + 3), for the LFE (slot 5) one byte each (bin = lane, lanes 0..6).
 // seq1 = lfsr_seq + 1 + the generator's position before the block's first draw (draw k is seq1[k]).
 // PS: floats from one plane of cblk to the next (256 in HBM; mantx_kernel's planes in LDS are padded).
-template <int PS = 256, class Fetch, class Cplco>
+// PK: a slot's end and gain come from MantBlk's packed fields (ends, gainv: one shift / one v_readlane) instead of the arrays;
+// mantx_kernel's choice - hipcc builds a tree of compares and branches per segment out of `slot == 0 ? gain[0] : ...` (240
+// scalar instructions per frame).  mant_kernel is compiled for 8 wavefronts per SIMD, which caps it at 78 scalar registers:
+// there the two extra 64-bit values cost more in spills than the trees (10.8 k -> 14.2 k vector instructions per frame), so it
+// keeps the arrays.
+template <int PS = 256, bool PK = false, class Fetch, class Cplco>
 __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2 first, Cplco cplco_of, const uint8_t *cplbnd, const uint4 *dsc, uint8_t *ring,
                                             const uint32_t *frw, uint32_t frw_last, const float *qtab, const int16_t *seq1, bool lfsr_live,
                                             float *cblk, uint32_t bitpos, int lane)
 {
     const int nf = B.nf;
     const int ncpl_dith = __popc(B.chincpl & B.dithmask);
-    const int remat_end = B.endmant[0] < B.endmant[1] ? B.endmant[0] : B.endmant[1];
+    const int em0 = PK ? (int)((uint32_t)B.ends & 0xffu) : B.endmant[0], em1 = PK ? (int)(((uint32_t)B.ends >> 8) & 0xffu) : B.endmant[1];
+    const int remat_end = em0 < em1 ? em0 : em1;
     const bool remat_late = B.acmod == 2 && B.rematflg != 0 && B.chincpl != 0 && remat_end > B.cplstrtmant;      // see mant_block
     const int cplfirst = B.chincpl ? __builtin_ctz(B.chincpl) : 99;
     const int nseg = nf + (B.chincpl ? 1 : 0) + (B.lfeon ? 1 : 0);
@@ -187,8 +193,9 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float q;
             seg2_values<1>(R, ring, qtab, &q);
-            const float v = q * (sf_of((int)(cur.y & 0xffu)) * B.lfe_gain);
-            const float z = 0.f * (sf_of(0) * B.lfe_gain);          // what the four-bin pass gives the bins past the seventh
+            const float lfe_gain = PK ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B.gainv), 5)) : B.lfe_gain;
+            const float v = q * (sf_of((int)(cur.y & 0xffu)) * lfe_gain);
+            const float z = 0.f * (sf_of(0) * lfe_gain);            // what the four-bin pass gives the bins past the seventh
             if (lane < 8) cblk[lane] = lane < 7 ? v : z;
             if (lane >= 2) *reinterpret_cast<float4 *>(cblk + 4 * lane) = make_float4(z, z, z, z);
             continue;
@@ -196,8 +203,13 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
         int start = 0, end, draws;
         float g = 0.f;
         if (slot < 5) {
-            end = slot == 0 ? B.endmant[0] : slot == 1 ? B.endmant[1] : slot == 2 ? B.endmant[2] : slot == 3 ? B.endmant[3] : B.endmant[4];
-            g = slot == 0 ? B.gain[0] : slot == 1 ? B.gain[1] : slot == 2 ? B.gain[2] : slot == 3 ? B.gain[3] : B.gain[4];
+            if (PK) {
+                end = (int)((uint32_t)(B.ends >> (8 * slot)) & 0xffu);
+                g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B.gainv), slot));
+            } else {
+                end = slot == 0 ? B.endmant[0] : slot == 1 ? B.endmant[1] : slot == 2 ? B.endmant[2] : slot == 3 ? B.endmant[3] : B.endmant[4];
+                g = slot == 0 ? B.gain[0] : slot == 1 ? B.gain[1] : slot == 2 ? B.gain[2] : slot == 3 ? B.gain[3] : B.gain[4];
+            }
             draws = (B.dithmask >> slot) & 1;
         } else {
             start = B.cplstrtmant;
@@ -278,7 +290,8 @@ __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2
                 uint32_t cdc = cd;
                 for (int c = 0; c < nf; c++) {
                     if (!((B.chincpl >> c) & 1)) continue;
-                    const float gc = c == 0 ? B.gain[0] : c == 1 ? B.gain[1] : c == 2 ? B.gain[2] : c == 3 ? B.gain[3] : B.gain[4];
+                    const float gc = PK ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B.gainv), c))
+                                        : c == 0 ? B.gain[0] : c == 1 ? B.gain[1] : c == 2 ? B.gain[2] : c == 3 ? B.gain[3] : B.gain[4];
                     const float co = cplco_of(c, bnd) * gc;
                     float v = m * co;
                     if (zero) {
