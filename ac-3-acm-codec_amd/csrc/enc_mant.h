@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t mant_pack_block(const MantBlock &B, const ui
             const uint32_t k8 = ((S >> 29) & 3u) * 8u;
             // code modulo 2^16 (:1365-1431): 9 q + 3 m1 + m2, 25 q + 5 m1 + m2, 11 q + m1 (+ the entry that is always 0)
             const uint32_t W0 = __builtin_amdgcn_ubfe(0x0b1909u, k8, 8u), W1 = __builtin_amdgcn_ubfe(0x010503u, k8, 8u);
-            const uint32_t code = (__umul24(S & 0xffffu, W0) + __umul24(mm[j] & 0xffffu, W1) + (mm[j] >> 16)) & 0xffffu;
+            const uint32_t code = (mul24_asm(S & 0xffffu, W0) + mul24_asm(mm[j] & 0xffffu, W1) + (mm[j] >> 16)) & 0xffffu;
             const uint32_t n0 = (S >> 24) & 31u;
             nb[j] = opens && code == B.marker ? 0u : n0;
             val[j] = opens ? code : S & 0xffffu;

@@ -35,6 +35,16 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
     return wave_last(v);
 }
 
+// a * b on the low 24 bits of both, as v_mul_u32_u24 and nothing else: where only the low bits of `__umul24(x & 0xffff, w)`
+// are used, hipcc drops the mask (the low bits of a product need only the low bits of the factors), then no longer knows the
+// factor is short and emits v_mul_lo_u32 - a quarter of the rate.
+__device__ __forceinline__ uint32_t mul24_asm(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Prefix minimum / maximum.  One `v_max_i32_dpp v, v, v` per step: a lane whose source lies outside its row (or whose row is
 // masked out) is left unwritten, which IS the identity - no identity register, no separate move.  hipcc does not form this
 // from __builtin_amdgcn_update_dpp + max (it emits v_mov_b32 identity, s_nop, v_mov_b32_dpp, v_max: four instructions per
