@@ -653,8 +653,8 @@ struct MantLDS {
 };
 
 #ifndef MANT_LB
-#define MANT_LB 8
-#endif
+#define MANT_LB 7       // (wavefronts per SIMD the register budget is set for: 8 -> 64 VGPRs but 78 scalar registers with 69 spilled,
+#endif                  //  7 -> 71 / 94 / 39, 6 -> 75 / 106 / 28; decode to s16 through this kernel 3.24 / 3.18 / 3.27 ms, round 4)
 __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
 {
     __shared__ MantLDS L;

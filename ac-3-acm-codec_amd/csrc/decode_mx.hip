@@ -13,6 +13,7 @@
 //
 // LDS per wavefront (MX_WAVE = 7296 bytes, used in turn): planes 6 x 272 floats + the code ring of the mantissa stage |
 // the six 8x16 transposes | tails (3 KB, read by the next wavefront) + the s16 tile (3 KB).
+#include <stdlib.h>
 #include "mant2.h"
 #include "xform_core.h"
 #include "ac3mi_internal.h"
@@ -301,7 +302,8 @@ hipError_t launch_mantx(const DeviceTables &tab, const DecodeLaunch &L, const Ma
     Q.window = tab.window;
     Q.bias = X.bias;
     for (int o = 0; o < 6; o++) Q.wslot[o] = 0;
-    const size_t dyn = (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4;
+    static const int lds_pad = getenv("AC3MI_MANTX_LDS_PAD") ? atoi(getenv("AC3MI_MANTX_LDS_PAD")) : 0;      // profiling aid: occupancy sweeps
+    const size_t dyn = (size_t)(((L.frame_bytes + 3) >> 2) + 6) * 4 + lds_pad;
     if (X.pcm16) {
         int map[6];
         if (s16_channel_map(X.s16_flags, map) != X.plan.n_out || ((uintptr_t)X.pcm16 & 15)) return hipErrorInvalidValue;
