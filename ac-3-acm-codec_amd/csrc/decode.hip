@@ -715,11 +715,12 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
     }
     {
         const uint32_t a = rfl(w1v.x), b = rfl(w1v.y), c = rfl(w1v.z), d = rfl(w1v.w);
-        B.endmant[0] = (int)(a & 0xffffu); B.endmant[1] = (int)(a >> 16); B.endmant[2] = (int)(b & 0xffffu); B.endmant[3] = (int)(b >> 16);
-        B.endmant[4] = (int)(c & 0xffffu); B.cplstrtmant = (int)(c >> 16); B.cplendmant = (int)(d & 0xffffu);
+        B.cplstrtmant = (int)(c >> 16); B.cplendmant = (int)(d & 0xffffu);
+        B.ends = (uint64_t)((a & 0xffu) | ((a >> 8) & 0xff00u) | ((b & 0xffu) << 16) | ((b << 8) & 0xff000000u)) | ((uint64_t)(c & 0xffu) << 32);
     }
-    B.gain[0] = __uint_as_float(rfl(w3v.x)); B.gain[1] = __uint_as_float(rfl(w3v.y)); B.gain[2] = __uint_as_float(rfl(w3v.z));
-    B.gain[3] = __uint_as_float(rfl(w3v.w)); B.gain[4] = __uint_as_float(rfl(w4v.x)); B.lfe_gain = __uint_as_float(rfl(w4v.y));
+    // the gains, lane k = slot k's (lane 5: the LFE's): one v_readlane per segment in mant_block2
+    B.gainv = lane == 0 ? __uint_as_float(w3v.x) : lane == 1 ? __uint_as_float(w3v.y) : lane == 2 ? __uint_as_float(w3v.z)
+            : lane == 3 ? __uint_as_float(w3v.w) : lane == 4 ? __uint_as_float(w4v.x) : __uint_as_float(w4v.y);
     if (B.chincpl && lane < 18) {                               // sub-band -> band (parse.c:448-456)
         const uint32_t below = rfl(w0v.w) & ((1u << lane) - 1u);
         L.cplbnd[blk][lane] = (uint8_t)(lane - __popc(below));
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(384, MANT_LB) void mant_kernel(const MantParams P)
     const bool lfsr_live = fpos != 0xffffffffu;
     const uint32_t i0 = lfsr_live ? (fpos + rfl(w0v.y)) % 65535u : 0u;            // the generator's position before the block's first draw
     const float *cc = P.cplco + unit * 90;
-    mant_block2(B, fetch, first, [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.dsc, L.ring[blk], frw, (uint32_t)nw + 2u,
+    mant_block2<256, true>(B, fetch, first, [&](int c, int bnd) { return cc[c * 18 + bnd]; }, L.cplbnd[blk], L.dsc, L.ring[blk], frw, (uint32_t)nw + 2u,
                 L.qtab, reinterpret_cast<const int16_t *>(P.lfsr_seq) + 1 + i0, lfsr_live, cblk, rfl(w0v.x), lane);
 }
 

@@ -158,11 +158,10 @@ __device__ __forceinline__ float dither2(const int16_t *seq, uint32_t i) { retur
 // one dword each (bins 4 lane .. 4 lane + 3), for the LFE (slot 5) one byte each (bin = lane, lanes 0..6).
 // seq1 = lfsr_seq + 1 + the generator's position before the block's first draw (draw k is seq1[k]).
 // PS: floats from one plane of cblk to the next (256 in HBM; mantx_kernel's planes in LDS are padded).
-// PK: a slot's end and gain come from MantBlk's packed fields (ends, gainv: one shift / one v_readlane) instead of the arrays;
-// mantx_kernel's choice - hipcc builds a tree of compares and branches per segment out of `slot == 0 ? gain[0] : ...` (240
-// scalar instructions per frame).  mant_kernel is compiled for 8 wavefronts per SIMD, which caps it at 78 scalar registers:
-// there the two extra 64-bit values cost more in spills than the trees (10.8 k -> 14.2 k vector instructions per frame), so it
-// keeps the arrays.
+// PK: a slot's end and gain come from MantBlk's packed fields (ends, gainv: one shift / one v_readlane) instead of the arrays -
+// hipcc builds a tree of compares and branches per segment out of `slot == 0 ? gain[0] : ...` (240 scalar instructions per
+// frame).  Both kernels use it since mant_kernel is compiled for 7 wavefronts per SIMD; at 8 its 78-register scalar budget made
+// the two extra 64-bit values cost more in spills than the trees (10.8 k -> 14.2 k vector instructions per frame).
 template <int PS = 256, bool PK = false, class Fetch, class Cplco>
 __device__ __forceinline__ void mant_block2(const MantBlk &B, Fetch fetch, uint2 first, Cplco cplco_of, const uint8_t *cplbnd, const uint4 *dsc, uint8_t *ring,
                                             const uint32_t *frw, uint32_t frw_last, const float *qtab, const int16_t *seq1, bool lfsr_live,
