@@ -581,6 +581,16 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
                 const auto r = __builtin_amdgcn_permlane16_swap((unsigned)pr, (unsigned)qr, false, false);
                 const auto i = __builtin_amdgcn_permlane16_swap((unsigned)pi, (unsigned)qi, false, false);
                 pr = (int)r[0]; qr = (int)r[1]; pi = (int)i[0]; qi = (int)i[1];
+            } else if constexpr (d == 4 || d == 8) {
+                // the DPP bank mask does the selecting: the lower lanes' q takes the partner's p, the upper lanes' p the
+                // partner's (old) q - four moves and two copies where selects around one move per component took eight to ten
+                constexpr int lo_banks = d == 4 ? 0x5 : 0x3, up_banks = d == 4 ? 0xa : 0xc;
+                constexpr int from_above = d == 4 ? 0x104 : 0x128, from_below = d == 4 ? 0x114 : 0x128;     // row_shl:4 / row_shr:4, row_ror:8
+                const int qr0 = qr, qi0 = qi;
+                qr = __builtin_amdgcn_update_dpp(qr, pr, from_above, 0xf, lo_banks, false);
+                qi = __builtin_amdgcn_update_dpp(qi, pi, from_above, 0xf, lo_banks, false);
+                pr = __builtin_amdgcn_update_dpp(pr, qr0, from_below, 0xf, up_banks, false);
+                pi = __builtin_amdgcn_update_dpp(pi, qi0, from_below, 0xf, up_banks, false);
             } else {
                 const bool up = (lane & d) != 0;
                 const int sr = up ? pr : qr, si = up ? pi : qi;
@@ -588,18 +598,10 @@ __global__ __launch_bounds__(64, ENC_MDCT_LB) void enc_mdct_kernel(const MdctPar
                 if constexpr (d == 1) {
                     rr = __builtin_amdgcn_update_dpp(0, sr, 0xb1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
                     ri = __builtin_amdgcn_update_dpp(0, si, 0xb1, 0xf, 0xf, false);
-                } else if constexpr (d == 2) {
+                } else {
+                    static_assert(d == 2, "");
                     rr = __builtin_amdgcn_update_dpp(0, sr, 0x4e, 0xf, 0xf, false);         // quad_perm [2,3,0,1]
                     ri = __builtin_amdgcn_update_dpp(0, si, 0x4e, 0xf, 0xf, false);
-                } else if constexpr (d == 4) {
-                    rr = __builtin_amdgcn_update_dpp(0, sr, 0x104, 0xf, 0x5, false);        // row_shl:4 into banks 0, 2
-                    rr = __builtin_amdgcn_update_dpp(rr, sr, 0x114, 0xf, 0xa, false);       // row_shr:4 into banks 1, 3
-                    ri = __builtin_amdgcn_update_dpp(0, si, 0x104, 0xf, 0x5, false);
-                    ri = __builtin_amdgcn_update_dpp(ri, si, 0x114, 0xf, 0xa, false);
-                } else {
-                    static_assert(d == 8, "");
-                    rr = __builtin_amdgcn_update_dpp(0, sr, 0x128, 0xf, 0xf, false);        // row_ror:8
-                    ri = __builtin_amdgcn_update_dpp(0, si, 0x128, 0xf, 0xf, false);
                 }
                 pr = up ? rr : pr; pi = up ? ri : pi;
                 qr = up ? qr : rr; qi = up ? qi : ri;
