@@ -76,7 +76,7 @@ def test_two_ranks_gloo():
 
 def test_rank_plan_fits_hbm():
     """What one rank plans for its shard (sharding.plan_transcode_bytes): the workspaces stop growing at the tile bound,
-    so BASELINE configs[4]'s per-GPU share (2^20 streams) needs ~30 GB, and a rank could hold about 25 M one-frame streams."""
+    so BASELINE configs[4]'s per-GPU share (2^20 streams) needs ~25 GB, and a rank could hold about 25 M one-frame streams."""
     sh = H.pkg().sharding
     lo, hi = sh.shard(8 * (1 << 20), 8, 5)
     p = sh.plan_transcode_bytes(hi - lo)
@@ -84,3 +84,8 @@ def test_rank_plan_fits_hbm():
     assert p["workspace"] == sh.plan_transcode_bytes(1 << 24)["workspace"]           # bounded by the tile
     assert sh.plan_transcode_bytes(4096)["workspace"] < p["workspace"]                # small batches: only what they use
     assert not sh.plan_transcode_bytes(40_000_000)["fits"]
+    # one-frame streams decode through the fused mantissa + transform kernel: no coefficient planes (6 blocks x 6 planes x 256
+    # floats per frame) in the workspace; streams of several frames keep them
+    one = sh.plan_transcode_bytes(65536, frames_per_stream=1)["workspace"]
+    two = sh.plan_transcode_bytes(32768, frames_per_stream=2)["workspace"]
+    assert two - one == 65536 * 6 * 6 * 256 * 4
